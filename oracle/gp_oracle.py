@@ -1,0 +1,490 @@
+"""CPU oracle for the edr-gp GP inference path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is the checker, never the product.  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import it.  The shipped path (``edr-gp_amd/``) never imports anything from
+``oracle/`` and fails loudly when its HIP library is missing.
+
+What it restates
+----------------
+The reference (``/root/reference``, neuro-ml/edr-gp 0.2.6) does no GP
+arithmetic itself: ``edrgp/gp_model/regression.py:76-77`` and ``:153-157``
+construct ``GPy.models.GPRegression`` / ``SparseGPRegression`` and
+``edrgp/gp_model/base.py:69,187,206,222`` call ``optimize``, ``predict`` and
+``predictive_gradients`` on them.  GPy (``gpy>=1.8.4``,
+``requirements.txt:3``, unpinned; paramz transitively) is a third-party
+dependency that is NOT under ``/root/reference`` and NOT installed in the build
+container, so the algorithm below is a restatement of GPy's published
+algorithm (GPy 1.9/1.10 sources: ``GPy/kern/src/stationary.py``, ``rbf.py``,
+``GPy/inference/latent_function_inference/{var_dtc,exact_gaussian_inference,
+posterior}.py``, ``GPy/core/{gp,sparse_gp}.py``, ``GPy/util/{linalg,
+normalizer}.py``, ``paramz/transformations.py``), issuing the same LAPACK/BLAS
+calls in the same order, with the same jitters (1e-8), clips and array shapes.
+
+Pinning status
+--------------
+The reference holds NO golden vectors or known-answer values for this path
+(``edrgp/tests/test_edr.py:33-117`` are five loose end-to-end invariants), and
+GPy cannot be run here, so parity with GPy itself is **unpinned**.  The oracle
+is pinned instead against independent known answers that exist in this
+container (``tests/test_oracle.py``): scikit-learn's exact GP
+log-marginal-likelihood / posterior (|d| ~ 1e-13), the VarDTC bound with Z = X
+versus the exact LML, the variational lower-bound property, central finite
+differences of the bound for every hyper-parameter and for Z, and finite
+differences of the posterior mean for ``predictive_gradients``.
+
+Every function cites the reference call site that reaches it and the GPy unit
+it restates.
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy import linalg
+from scipy.linalg import lapack
+
+LOG_2_PI = np.log(2.0 * np.pi)
+CONST_JITTER = 1e-8          # GPy VarDTC.const_jitter; ExactGaussianInference adds 1e-8 too
+
+KINDS = ("RBF", "Matern32", "Matern52")
+
+
+# --------------------------------------------------------------------------
+# GPy.util.linalg
+# --------------------------------------------------------------------------
+def jitchol(A, maxtries=5):
+    """GPy.util.linalg.jitchol: dpotrf, on failure retry with jitter
+    mean(diag)*1e-6*10^k, k < maxtries.  Reached from VarDTC.inference /
+    pdinv on every ``fit`` iteration (gp_model/base.py:69)."""
+    A = np.ascontiguousarray(A)
+    L, info = lapack.dpotrf(A, lower=1)
+    if info == 0:
+        return L
+    diagA = np.diag(A)
+    if np.any(diagA <= 0.0):
+        raise linalg.LinAlgError("not pd: non-positive diagonal elements")
+    jitter = diagA.mean() * 1e-6
+    num_tries = 1
+    while num_tries <= maxtries and np.isfinite(jitter):
+        try:
+            return linalg.cholesky(A + np.eye(A.shape[0]) * jitter, lower=True)
+        except linalg.LinAlgError:
+            jitter *= 10
+        finally:
+            num_tries += 1
+    raise linalg.LinAlgError("not positive definite, even with jitter.")
+
+
+def dtrtrs(A, B, lower=1, trans=0):
+    """GPy.util.linalg.dtrtrs -> LAPACK dtrtrs (solve op(A) X = B, A triangular)."""
+    A = np.asfortranarray(A)
+    return lapack.dtrtrs(A, B, lower=lower, trans=trans, unitdiag=0)[0]
+
+
+def dpotrs(L, B, lower=1):
+    """GPy.util.linalg.dpotrs -> LAPACK dpotrs."""
+    return lapack.dpotrs(np.asfortranarray(L), B, lower=lower)[0]
+
+
+def dpotri(L, lower=1):
+    """GPy.util.linalg.dpotri -> LAPACK dpotri; returns the symmetrised inverse."""
+    Ai = lapack.dpotri(np.asfortranarray(L), lower=lower)[0]
+    Ai = np.tril(Ai) + np.tril(Ai, -1).T if lower else np.triu(Ai) + np.triu(Ai, 1).T
+    return Ai
+
+
+def tdot(A):
+    """GPy.util.linalg.tdot: A A^T (dsyrk upstream)."""
+    return A @ A.T
+
+
+def backsub_both_sides(L, X, transpose="left"):
+    """GPy.util.linalg.backsub_both_sides: L^-T X L^-1 ('left', the default)
+    or L^-1 X L^-T, X symmetric, L lower Cholesky."""
+    if transpose == "left":
+        tmp = dtrtrs(L, X, lower=1, trans=1)
+        return dtrtrs(L, tmp.T, lower=1, trans=1).T
+    tmp = dtrtrs(L, X, lower=1, trans=0)
+    return dtrtrs(L, tmp.T, lower=1, trans=0).T
+
+
+def pdinv(A):
+    """GPy.util.linalg.pdinv: (Ai, L, Li, logdet)."""
+    L = jitchol(A)
+    logdet = 2.0 * np.sum(np.log(np.diag(L)))
+    Li = dtrtrs(L, np.eye(A.shape[0]), lower=1)
+    Ai = dpotri(L, lower=1)
+    return Ai, L, Li, logdet
+
+
+# --------------------------------------------------------------------------
+# GPy.util.normalizer.Standardize   (normalizer=True, regression.py:48,124)
+# --------------------------------------------------------------------------
+class Standardize:
+    def scale_by(self, Y):
+        Y = np.asarray(Y, dtype=np.float64)
+        self.mean = Y.mean(0)
+        self.std = Y.std(0)            # ddof = 0
+
+    def normalize(self, Y):
+        return (Y - self.mean) / self.std
+
+    def inverse_mean(self, X):
+        return X * self.std + self.mean
+
+    def inverse_variance(self, var):
+        return var * self.std ** 2
+
+
+# --------------------------------------------------------------------------
+# paramz.transformations.Logexp  (positive parameters under optimisation)
+# --------------------------------------------------------------------------
+_LIM_VAL = 36.0
+_EPS = np.finfo(np.float64).resolution
+
+
+class Logexp:
+    @staticmethod
+    def f(x):
+        x = np.asarray(x, dtype=np.float64)
+        return np.where(x > _LIM_VAL, x, np.log1p(np.exp(np.clip(x, -np.log(np.finfo(np.float64).max), _LIM_VAL))))
+
+    @staticmethod
+    def finv(f):
+        f = np.asarray(f, dtype=np.float64)
+        return np.where(f > _LIM_VAL, f, np.log(np.expm1(f)))
+
+    @staticmethod
+    def gradfactor(f, df):
+        f = np.asarray(f, dtype=np.float64)
+        return df * np.where(f > _LIM_VAL, 1.0, -np.expm1(-f))
+
+
+# --------------------------------------------------------------------------
+# GPy.kern.src.stationary.Stationary / rbf.RBF / Matern32 / Matern52
+# (built by _make_kernel, gp_model/base.py:111-147; default RBF, :120-122)
+# --------------------------------------------------------------------------
+class Stationary:
+    def __init__(self, kind, input_dim, variance=1.0, lengthscale=None, ARD=False):
+        assert kind in KINDS, kind
+        self.kind = kind
+        self.input_dim = int(input_dim)
+        self.ARD = bool(ARD)
+        self.variance = float(variance)
+        if lengthscale is None:
+            lengthscale = np.ones(self.input_dim if self.ARD else 1)
+        lengthscale = np.atleast_1d(np.asarray(lengthscale, dtype=np.float64))
+        if self.ARD and lengthscale.size == 1:
+            lengthscale = np.ones(self.input_dim) * lengthscale
+        if not self.ARD:
+            assert lengthscale.size == 1, "Only 1 lengthscale needed for non-ARD kernel"
+        self.lengthscale = lengthscale.copy()
+
+    # -- distances ---------------------------------------------------------
+    def _unscaled_dist(self, X, X2=None):
+        if X2 is None:
+            Xsq = np.sum(np.square(X), 1)
+            r2 = -2.0 * tdot(X) + (Xsq[:, None] + Xsq[None, :])
+            r2[np.diag_indices_from(r2)] = 0.0      # util.diag.view(r2)[:,] = 0.
+            r2 = np.clip(r2, 0, np.inf)
+            return np.sqrt(r2)
+        X1sq = np.sum(np.square(X), 1)
+        X2sq = np.sum(np.square(X2), 1)
+        r2 = -2.0 * np.dot(X, X2.T) + (X1sq[:, None] + X2sq[None, :])
+        r2 = np.clip(r2, 0, np.inf)
+        return np.sqrt(r2)
+
+    def _scaled_dist(self, X, X2=None):
+        if self.ARD:
+            if X2 is not None:
+                X2 = X2 / self.lengthscale
+            return self._unscaled_dist(X / self.lengthscale, X2)
+        return self._unscaled_dist(X, X2) / self.lengthscale
+
+    def _inv_dist(self, X, X2=None):
+        dist = self._scaled_dist(X, X2).copy()
+        return 1.0 / np.where(dist != 0.0, dist, np.inf)
+
+    # -- covariance as a function of r --------------------------------------
+    def K_of_r(self, r):
+        v = self.variance
+        if self.kind == "RBF":
+            return v * np.exp(-0.5 * r ** 2)
+        if self.kind == "Matern32":
+            return v * (1.0 + np.sqrt(3.0) * r) * np.exp(-np.sqrt(3.0) * r)
+        return v * (1 + np.sqrt(5.0) * r + 5.0 / 3 * r ** 2) * np.exp(-np.sqrt(5.0) * r)
+
+    def dK_dr(self, r):
+        v = self.variance
+        if self.kind == "RBF":
+            return -r * self.K_of_r(r)
+        if self.kind == "Matern32":
+            return -3.0 * v * r * np.exp(-np.sqrt(3.0) * r)
+        return v * (10.0 / 3 * r - 5.0 * r - 5.0 * np.sqrt(5.0) / 3 * r ** 2) * np.exp(-np.sqrt(5.0) * r)
+
+    def K(self, X, X2=None):
+        return self.K_of_r(self._scaled_dist(X, X2))
+
+    def Kdiag(self, X):
+        ret = np.empty(X.shape[0])
+        ret[:] = self.variance
+        return ret
+
+    def dK_dr_via_X(self, X, X2):
+        return self.dK_dr(self._scaled_dist(X, X2))
+
+    # -- gradients -----------------------------------------------------------
+    def gradients_X(self, dL_dK, X, X2=None):
+        """Stationary._gradients_X_pure (upstream also has a Cython/OpenMP twin)."""
+        invdist = self._inv_dist(X, X2)
+        dL_dr = self.dK_dr_via_X(X, X2) * dL_dK
+        tmp = invdist * dL_dr
+        if X2 is None:
+            tmp = tmp + tmp.T
+            X2 = X
+        grad = np.empty(X.shape, dtype=np.float64)
+        for q in range(self.input_dim):
+            np.sum(tmp * (X[:, q][:, None] - X2[:, q][None, :]), axis=1, out=grad[:, q])
+        return grad / self.lengthscale ** 2
+
+    def param_gradients_full(self, dL_dK, X, X2=None):
+        """Stationary.update_gradients_full -> (d/dvariance, d/dlengthscale)."""
+        dvar = np.sum(self.K(X, X2) * dL_dK) / self.variance
+        dL_dr = self.dK_dr_via_X(X, X2) * dL_dK
+        if self.ARD:
+            tmp = dL_dr * self._inv_dist(X, X2)
+            if X2 is None:
+                X2 = X
+            dl = -np.array([np.sum(tmp * np.square(X[:, q:q + 1] - X2[:, q:q + 1].T))
+                            for q in range(self.input_dim)]) / self.lengthscale ** 3
+        else:
+            r = self._scaled_dist(X, X2)
+            dl = np.atleast_1d(-np.sum(dL_dr * r) / self.lengthscale)
+        return dvar, dl
+
+    def param_gradients_diag(self, dL_dKdiag, X):
+        """Stationary.update_gradients_diag."""
+        return np.sum(dL_dKdiag), np.zeros_like(self.lengthscale)
+
+    def n_params(self):
+        return 1 + self.lengthscale.size
+
+
+class Add:
+    """GPy.kern.Add of stationary parts (``np.sum([...])`` at gp_model/base.py:146)."""
+
+    def __init__(self, parts):
+        self.parts = list(parts)
+        self.input_dim = self.parts[0].input_dim
+
+    def K(self, X, X2=None):
+        return sum(p.K(X, X2) for p in self.parts)
+
+    def Kdiag(self, X):
+        return sum(p.Kdiag(X) for p in self.parts)
+
+    def gradients_X(self, dL_dK, X, X2=None):
+        return sum(p.gradients_X(dL_dK, X, X2) for p in self.parts)
+
+    def param_gradients_full(self, dL_dK, X, X2=None):
+        return [p.param_gradients_full(dL_dK, X, X2) for p in self.parts]
+
+    def param_gradients_diag(self, dL_dKdiag, X):
+        return [p.param_gradients_diag(dL_dKdiag, X) for p in self.parts]
+
+
+def as_add(kern):
+    return kern if isinstance(kern, Add) else Add([kern])
+
+
+def make_kernel(kinds, input_dim, options=None):
+    """_BaseGP._make_kernel (gp_model/base.py:111-147) for the stationary family."""
+    if kinds is None:
+        kinds = ["RBF"]
+    if isinstance(kinds, str):
+        kinds = [kinds]
+    if isinstance(options, dict):
+        options = [options]
+    if options is None:
+        options = [{}] * len(kinds)
+    if len(options) != len(kinds):
+        raise ValueError
+    return Add([Stationary(k, input_dim, **o) for k, o in zip(kinds, options)])
+
+
+# --------------------------------------------------------------------------
+# GPy.inference.latent_function_inference.var_dtc.VarDTC.inference
+# (SparseGPRegression built at regression.py:153-157; evaluated once per
+#  optimiser iteration from gp_model/base.py:69)
+# --------------------------------------------------------------------------
+def vardtc_inference(kern, X, Z, noise_var, Y):
+    """Returns dict with the Titsias bound (shape (1,1), as the reference's
+    test reads it: tests/test_edr.py:50), posterior factors and dL_d* terms.
+    Same operation sequence as upstream: Kmm+jitter -> jitchol; psi1 = K(X,Z);
+    dtrtrs; tdot; jitchol(B); dtrtrs x2; ..."""
+    kern = as_add(kern)
+    num_data, output_dim = Y.shape
+    num_inducing = Z.shape[0]
+    precision = 1.0 / np.fmax(np.atleast_1d(np.float64(noise_var)), CONST_JITTER)
+    precision = precision[:, None]                                   # (1,1)
+    VVT_factor = precision * Y
+    trYYT = np.einsum("ij,ij->", Y, Y)
+
+    Kmm = kern.K(Z).copy()
+    Kmm[np.diag_indices_from(Kmm)] += CONST_JITTER
+    Lm = jitchol(Kmm)
+
+    psi0 = kern.Kdiag(X)
+    psi1 = kern.K(X, Z)
+    tmp = psi1 * np.sqrt(precision)
+    tmp = dtrtrs(Lm, tmp.T, lower=1)
+    A = tdot(tmp)
+
+    B = np.eye(num_inducing) + A
+    LB = jitchol(B)
+
+    tmp = dtrtrs(Lm, psi1.T, lower=1, trans=0)
+    _LBi_Lmi_psi1 = dtrtrs(LB, tmp, lower=1, trans=0)
+    _LBi_Lmi_psi1Vf = np.dot(_LBi_Lmi_psi1, VVT_factor)
+    tmp = dtrtrs(LB, _LBi_Lmi_psi1Vf, lower=1, trans=1)
+    Cpsi1Vf = dtrtrs(Lm, tmp, lower=1, trans=1)
+
+    delit = tdot(_LBi_Lmi_psi1Vf)
+    data_fit = np.trace(delit)
+    DBi_plus_BiPBi = backsub_both_sides(LB, output_dim * np.eye(num_inducing) + delit)
+    delit = -0.5 * DBi_plus_BiPBi
+    delit += -0.5 * B * output_dim
+    delit += output_dim * np.eye(num_inducing)
+    dL_dKmm = backsub_both_sides(Lm, delit)
+
+    # _compute_dL_dpsi
+    dL_dpsi0 = -0.5 * output_dim * (precision * np.ones([num_data, 1])).flatten()
+    dL_dpsi1 = np.dot(VVT_factor, Cpsi1Vf.T)
+    dL_dpsi2_beta = 0.5 * backsub_both_sides(Lm, output_dim * np.eye(num_inducing) - DBi_plus_BiPBi)
+    dL_dpsi2 = precision * dL_dpsi2_beta
+    dL_dpsi1 += 2.0 * np.dot(psi1, dL_dpsi2)
+
+    # _compute_log_marginal_likelihood
+    beta = precision
+    lik_1 = -0.5 * num_data * output_dim * (LOG_2_PI - np.log(beta)) - 0.5 * beta * trYYT
+    lik_2 = -0.5 * output_dim * (np.sum(beta * psi0) - np.trace(A))
+    lik_3 = -output_dim * (np.sum(np.log(np.diag(LB))))
+    lik_4 = 0.5 * data_fit
+    log_marginal = lik_1 + lik_2 + lik_3 + lik_4                      # (1,1)
+
+    # _compute_dL_dR  (homoscedastic)
+    dL_dR = -0.5 * num_data * output_dim * beta + 0.5 * trYYT * beta ** 2
+    dL_dR += 0.5 * output_dim * (psi0.sum() * beta ** 2 - np.trace(A) * beta)
+    dL_dR += beta * (0.5 * np.sum(A * DBi_plus_BiPBi) - data_fit)
+    dL_dthetaL = float(np.sum(dL_dR))      # Gaussian.exact_inference_gradients = sum
+
+    woodbury_vector = Cpsi1Vf
+    Bi = -dpotri(LB, lower=1)
+    Bi[np.diag_indices_from(Bi)] += 1.0
+    woodbury_inv = backsub_both_sides(Lm, Bi)
+
+    return dict(log_marginal=log_marginal, woodbury_vector=woodbury_vector,
+                woodbury_inv=woodbury_inv, Lm=Lm, LB=LB, A=A, Kmm=Kmm, psi1=psi1,
+                dL_dKmm=dL_dKmm, dL_dKnm=dL_dpsi1, dL_dKdiag=dL_dpsi0,
+                dL_dthetaL=dL_dthetaL, data_fit=data_fit)
+
+
+def sparse_gradients(kern, X, Z, inf):
+    """SparseGP._update_gradients (GPy/core/sparse_gp.py): kernel, noise and
+    inducing-input gradients of the bound.  Returns (kern_grads, dnoise, dZ)
+    with kern_grads = [(dvariance, dlengthscale), ...] per additive part."""
+    kern = as_add(kern)
+    g_diag = kern.param_gradients_diag(inf["dL_dKdiag"], X)
+    g_nm = kern.param_gradients_full(inf["dL_dKnm"], X, Z)
+    g_mm = kern.param_gradients_full(inf["dL_dKmm"], Z, None)
+    kern_grads = [(a[0] + b[0] + c[0], a[1] + b[1] + c[1]) for a, b, c in zip(g_diag, g_nm, g_mm)]
+    dZ = kern.gradients_X(inf["dL_dKmm"], Z)
+    dZ = dZ + kern.gradients_X(inf["dL_dKnm"].T, Z, X)
+    return kern_grads, inf["dL_dthetaL"], dZ
+
+
+# --------------------------------------------------------------------------
+# GPy.inference.latent_function_inference.exact_gaussian_inference
+# (GPRegression built at regression.py:76-77)
+# --------------------------------------------------------------------------
+def exact_inference(kern, X, noise_var, Y):
+    kern = as_add(kern)
+    K = kern.K(X)
+    Ky = K.copy()
+    Ky[np.diag_indices_from(Ky)] += noise_var + 1e-8
+    Wi, LW, LWi, W_logdet = pdinv(Ky)
+    alpha = dpotrs(LW, Y, lower=1)
+    log_marginal = 0.5 * (-Y.size * LOG_2_PI - Y.shape[1] * W_logdet - np.sum(alpha * Y))
+    dL_dK = 0.5 * (tdot(alpha) - Y.shape[1] * Wi)
+    dL_dthetaL = float(np.sum(np.diag(dL_dK)))
+    return dict(log_marginal=float(log_marginal), woodbury_vector=alpha, woodbury_chol=LW,
+                woodbury_inv=Wi, K=K, dL_dK=dL_dK, dL_dthetaL=dL_dthetaL)
+
+
+def dense_gradients(kern, X, inf):
+    """GP.parameters_changed: kern.update_gradients_full(dL_dK, X)."""
+    kern = as_add(kern)
+    return kern.param_gradients_full(inf["dL_dK"], X, None), inf["dL_dthetaL"]
+
+
+# --------------------------------------------------------------------------
+# Posterior._raw_predict + GP.predict + GP.predictive_gradients
+# (gp_model/base.py:187, :206, :222)
+# --------------------------------------------------------------------------
+def raw_predict(kern, Xnew, pred_var, woodbury_vector, woodbury_inv):
+    kern = as_add(kern)
+    Kx = kern.K(pred_var, Xnew)
+    mu = np.dot(Kx.T, woodbury_vector)
+    Kxx = kern.Kdiag(Xnew)
+    var = (Kxx - np.sum(np.dot(woodbury_inv.T, Kx) * Kx, 0))[:, None]
+    var = np.clip(var, 1e-15, np.inf)
+    return mu, var
+
+
+def predict(kern, Xnew, pred_var, woodbury_vector, woodbury_inv, noise_var, normalizer=None):
+    """GP.predict: latent moments -> + Gaussian noise -> Standardize inverse."""
+    mu, var = raw_predict(kern, Xnew, pred_var, woodbury_vector, woodbury_inv)
+    var = var + noise_var
+    if normalizer is not None:
+        mu = normalizer.inverse_mean(mu)
+        var = normalizer.inverse_variance(var)
+    return mu, var
+
+
+def predictive_gradients_mean(kern, Xnew, pred_var, woodbury_vector, normalizer=None):
+    """Mean part of GP.predictive_gradients -> (N*, D, 1).  The variance part
+    is computed upstream and discarded by the reference (``[0]`` at
+    gp_model/base.py:222).  Newer GPy rescales the Jacobian by the
+    normaliser's std (gradient of the un-normalised mean); that behaviour is
+    the one restated (a global scalar: EDR directions are invariant to it)."""
+    kern = as_add(kern)
+    mean_jac = np.empty((Xnew.shape[0], Xnew.shape[1], woodbury_vector.shape[1]))
+    for i in range(woodbury_vector.shape[1]):
+        mean_jac[:, :, i] = kern.gradients_X(woodbury_vector[:, i:i + 1].T, Xnew, pred_var)
+    if normalizer is not None:
+        mean_jac = mean_jac * normalizer.std
+    return mean_jac
+
+
+# --------------------------------------------------------------------------
+# The lean (Gram-only) formulation the HIP path uses, restated on the CPU so
+# tests can compare intermediate objects (Phi, b) as well as end results.
+# Mathematically identical to vardtc_inference; see DESIGN.md.
+# --------------------------------------------------------------------------
+def gram_stats(kern, X, Z, Y):
+    kern = as_add(kern)
+    psi1 = kern.K(X, Z)
+    return dict(Phi=psi1.T @ psi1, b=psi1.T @ Y, yy=float(np.sum(Y * Y)),
+                psi0=float(np.sum(kern.Kdiag(X))))
+
+
+def synthetic_problem(N, D, M, seed=0, dtype=np.float64):
+    """SURVEY.md section 8(d) deterministic synthetic inputs: X ~ N(0, I);
+    y = tanh(X w) + 0.05 eps, w = 1/sqrt(D) (functional form of
+    edrgp/datasets.py:25-31), standardised (ddof 0); Z = X[perm[:M]]."""
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((N, D)).astype(dtype)
+    w = np.ones(D) / np.sqrt(D)
+    y = np.tanh(X @ w) + 0.05 * rng.standard_normal(N)
+    y = (y - y.mean()) / y.std()
+    Z = X[rng.permutation(N)[:M]].copy()
+    return X, y.astype(dtype), Z
