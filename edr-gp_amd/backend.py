@@ -1,0 +1,208 @@
+"""Python handle on one native context (one HIP device, one stream).
+
+Thin: every method is one C-ABI call (include/edrgp_hip.h).  Arrays cross the
+boundary as row-major float64; training data is copied to HBM once by
+``set_data`` and stays resident across evaluations.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import KERN_CODES, as_f64, check, dptr
+
+
+class HipGP:
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        self._ctx = ctypes.c_void_p()
+        check(self._lib.edrgp_ctx_create(int(device), ctypes.byref(self._ctx)))
+        self.device = int(device)
+        self.N = self.D = self.M = 0
+        self.nparts = 0
+
+    # -- lifetime ----------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self._lib.edrgp_ctx_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(self._lib.edrgp_sync(self._ctx))
+
+    def set_option(self, key, value):
+        check(self._lib.edrgp_set_option(self._ctx, key.encode(), float(value)))
+
+    # -- state -------------------------------------------------------------
+    def set_data(self, X, y):
+        X = as_f64(X)
+        y = as_f64(np.ravel(y))
+        if X.ndim != 2 or y.shape[0] != X.shape[0]:
+            raise ValueError("X must be (N, D) and y (N,)")
+        check(self._lib.edrgp_set_data(self._ctx, dptr(X), dptr(y), X.shape[0], X.shape[1]))
+        self.N, self.D = X.shape
+
+    def set_inducing(self, Z):
+        Z = as_f64(Z)
+        if Z.ndim != 2 or Z.shape[1] != self.D:
+            raise ValueError("Z must be (M, %d)" % self.D)
+        check(self._lib.edrgp_set_inducing(self._ctx, dptr(Z), Z.shape[0]))
+        self.M = Z.shape[0]
+
+    def set_kernel(self, kinds, variances, lengthscales, noise_var):
+        """kinds: list of names; lengthscales: (nparts, D) expanded per dimension."""
+        codes = np.ascontiguousarray([KERN_CODES[k] for k in kinds], dtype=np.int32)
+        var = as_f64(variances).ravel()
+        ls = as_f64(lengthscales).reshape(len(kinds), self.D)
+        check(self._lib.edrgp_set_kernel(self._ctx, len(kinds), codes.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
+                                         dptr(var), dptr(ls), float(noise_var)))
+        self.nparts = len(kinds)
+
+    # -- evaluations -------------------------------------------------------
+    def sparse_lml(self):
+        out = ctypes.c_double(0.0)
+        check(self._lib.edrgp_sparse_lml(self._ctx, ctypes.byref(out)))
+        return out.value
+
+    def sparse_lml_grad(self):
+        lml = ctypes.c_double(0.0)
+        dnoise = ctypes.c_double(0.0)
+        dvar = np.zeros(self.nparts)
+        dlen = np.zeros((self.nparts, self.D))
+        dZ = np.zeros((self.M, self.D))
+        check(self._lib.edrgp_sparse_lml_grad(self._ctx, ctypes.byref(lml), dptr(dvar), dptr(dlen),
+                                              ctypes.byref(dnoise), dptr(dZ)))
+        return lml.value, dvar, dlen, dnoise.value, dZ
+
+    def sparse_posterior(self):
+        out = ctypes.c_double(0.0)
+        check(self._lib.edrgp_sparse_posterior(self._ctx, ctypes.byref(out)))
+        return out.value
+
+    def dense_lml(self):
+        out = ctypes.c_double(0.0)
+        check(self._lib.edrgp_dense_lml_grad(self._ctx, ctypes.byref(out), None, None, None))
+        return out.value
+
+    def dense_lml_grad(self):
+        lml = ctypes.c_double(0.0)
+        dnoise = ctypes.c_double(0.0)
+        dvar = np.zeros(self.nparts)
+        dlen = np.zeros((self.nparts, self.D))
+        check(self._lib.edrgp_dense_lml_grad(self._ctx, ctypes.byref(lml), dptr(dvar), dptr(dlen),
+                                             ctypes.byref(dnoise)))
+        return lml.value, dvar, dlen, dnoise.value
+
+    def dense_posterior(self):
+        out = ctypes.c_double(0.0)
+        check(self._lib.edrgp_dense_posterior(self._ctx, ctypes.byref(out)))
+        return out.value
+
+    # -- prediction (latent, normalised space) -----------------------------
+    def predict(self, Xs, want_var=True):
+        Xs = as_f64(Xs)
+        mean = np.empty(Xs.shape[0])
+        var = np.empty(Xs.shape[0]) if want_var else None
+        check(self._lib.edrgp_predict(self._ctx, dptr(Xs), Xs.shape[0], dptr(mean), dptr(var)))
+        return mean, var
+
+    def predict_grad(self, Xs):
+        Xs = as_f64(Xs)
+        grad = np.empty((Xs.shape[0], self.D))
+        check(self._lib.edrgp_predict_grad(self._ctx, dptr(Xs), Xs.shape[0], dptr(grad)))
+        return grad
+
+    def predict_train(self, want_mean=True, want_grad=True):
+        mean = np.empty(self.N) if want_mean else None
+        grad = np.empty((self.N, self.D)) if want_grad else None
+        check(self._lib.edrgp_predict_train(self._ctx, dptr(mean), dptr(grad)))
+        return mean, grad
+
+    # -- parity / profiling accessors --------------------------------------
+    def get(self, name, shape):
+        buf = np.empty(shape)
+        check(self._lib.edrgp_get(self._ctx, _lib.GET[name], dptr(buf), buf.size))
+        return buf
+
+    def profile_reset(self):
+        check(self._lib.edrgp_profile_reset(self._ctx))
+
+    def profile_get(self, name):
+        ms = ctypes.c_double(0.0)
+        n = ctypes.c_int64(0)
+        check(self._lib.edrgp_profile_get(self._ctx, _lib.PROF[name], ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    def calib(self):
+        tf = ctypes.c_double(0.0)
+        bw = ctypes.c_double(0.0)
+        check(self._lib.edrgp_calib(self._ctx, ctypes.byref(tf), ctypes.byref(bw)))
+        return tf.value, bw.value
+
+    # -- multi-GPU ----------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = ctypes.create_string_buffer(128)
+        check(_lib.load().edrgp_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, nranks, rank, unique_id):
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        check(self._lib.edrgp_comm_init(self._ctx, int(nranks), int(rank), buf))
+
+    def comm_destroy(self):
+        check(self._lib.edrgp_comm_destroy(self._ctx))
+
+    # -- low-level test hooks -----------------------------------------------
+    def dbg_gemm(self, A, B, transA=False, transB=False, alpha=1.0, beta=0.0, C=None):
+        A = as_f64(A)
+        B = as_f64(B)
+        M = A.shape[1] if transA else A.shape[0]
+        K = A.shape[0] if transA else A.shape[1]
+        N = B.shape[0] if transB else B.shape[1]
+        out = np.zeros((M, N)) if C is None else as_f64(C).copy()
+        check(self._lib.edrgp_dbg_gemm(self._ctx, int(transA), int(transB), M, N, K, float(alpha), dptr(A),
+                                       A.shape[1], dptr(B), B.shape[1], float(beta), dptr(out), N))
+        return out
+
+    def dbg_potrf(self, A):
+        L = as_f64(A).copy()
+        info = ctypes.c_int(0)
+        check(self._lib.edrgp_dbg_potrf(self._ctx, dptr(L), L.shape[0], ctypes.byref(info)))
+        return L, info.value
+
+    def dbg_trtri(self, L):
+        L = as_f64(L)
+        out = np.empty_like(L)
+        check(self._lib.edrgp_dbg_trtri(self._ctx, dptr(L), dptr(out), L.shape[0]))
+        return out
+
+    def dbg_syrk(self, K):
+        K = as_f64(K)
+        out = np.empty((K.shape[1], K.shape[1]))
+        check(self._lib.edrgp_dbg_syrk(self._ctx, dptr(K), K.shape[0], K.shape[1], dptr(out)))
+        return out
+
+    def dbg_kernel_matrix(self, X, X2=None):
+        X = as_f64(X)
+        n2 = X.shape[0] if X2 is None else X2.shape[0]
+        X2c = None if X2 is None else as_f64(X2)
+        out = np.empty((X.shape[0], n2))
+        check(self._lib.edrgp_dbg_kernel_matrix(self._ctx, dptr(X), X.shape[0], dptr(X2c), n2, X.shape[1],
+                                                dptr(out)))
+        return out
+
+    def dbg_mfma_layout(self, A16x4, B4x16):
+        A = as_f64(A16x4)
+        B = as_f64(B4x16)
+        out = np.empty((16, 16))
+        check(self._lib.edrgp_dbg_mfma_layout(self._ctx, dptr(A), dptr(B), dptr(out)))
+        return out

@@ -1,0 +1,64 @@
+"""Build libedrgp_hip.so (gfx950) in-tree with hipcc.
+
+``python edr-gp_amd/build.py`` or ``build_library()`` from ``__graft_entry__``.
+The shared object is git-ignored but travels to the GPU box with the snapshot.
+Objects are rebuilt only when a source or header is newer than the object.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "csrc", "_obj")
+LIB = os.path.join(HERE, "libedrgp_hip.so")
+SOURCES = ["api.hip", "la_gemm.hip", "la_chol.hip", "la_vec.hip", "gp_kernels.hip", "comm.hip", "calib.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "edrgp_hip.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result",
+         "-I/opt/rocm/include"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src):
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    path = os.path.join(CSRC, src)
+    if _stale(obj, [path] + HEADERS):
+        cmd = [HIPCC] + FLAGS + ["-c", path, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+        return obj, True
+    return obj, False
+
+
+def build_library(verbose=False, jobs=4):
+    os.makedirs(OBJ, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        results = list(ex.map(_compile, SOURCES))
+    objs = [o for o, _ in results]
+    if any(changed for _, changed in results) or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + \
+              ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        if verbose:
+            print("built", LIB)
+    elif verbose:
+        print("up to date:", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_library(verbose=True)
+    sys.exit(0)

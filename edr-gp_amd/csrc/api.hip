@@ -1,0 +1,949 @@
+// C-ABI entry points and the host-side orchestration of the GP inference
+// pipelines (include/edrgp_hip.h).  The operation sequence restates GPy
+// VarDTC.inference / ExactGaussianInference.inference / Posterior._raw_predict
+// in the lean Gram form: everything O(N) is a tile build
+// plus MFMA contractions, everything O(M^3) is MFMA GEMMs around two blocked
+// Choleskys with explicit triangular inverses.
+#include "common.h"
+#include <cmath>
+#include <cstring>
+#include <algorithm>
+
+namespace edrgp {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+int DBuf::reserve(size_t need) {
+    if (need <= bytes && p != nullptr) return EDRGP_OK;
+    if (need == 0) need = 8;
+    if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+    hipError_t e = hipMalloc(&p, need);
+    if (e != hipSuccess) {
+        p = nullptr;
+        set_error("hipMalloc(%zu bytes) failed: %s", need, hipGetErrorString(e));
+        return EDRGP_ERR_HIP;
+    }
+    bytes = need;
+    return EDRGP_OK;
+}
+
+void DBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+}
+
+ProfScope::ProfScope(Ctx* c_, int slot_) : c(c_), slot(slot_) {
+    if (!c->profile) return;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
+    (void)hipEventRecord(e0, c->stream);
+}
+
+ProfScope::~ProfScope() {
+    if (!e0) return;
+    (void)hipEventRecord(e1, c->stream);
+    c->pending_events.push_back({slot, {e0, e1}});
+}
+
+int Ctx::drain_events() {
+    for (auto& pe : pending_events) {
+        float ms = 0.f;
+        if (hipEventSynchronize(pe.second.second) == hipSuccess &&
+            hipEventElapsedTime(&ms, pe.second.first, pe.second.second) == hipSuccess) {
+            prof[pe.first].total_ms += ms;
+            prof[pe.first].launches += 1;
+        }
+        (void)hipEventDestroy(pe.second.first);
+        (void)hipEventDestroy(pe.second.second);
+    }
+    pending_events.clear();
+    return EDRGP_OK;
+}
+
+__global__ void axpy_kernel(int64_t n, double a, const double* __restrict__ x, double* __restrict__ y) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] += a * x[i];
+}
+
+int vec_axpy(Ctx* c, int64_t n, double a, const double* x, double* y) {
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (n + 255) / 256));
+    hipLaunchKernelGGL(axpy_kernel, dim3(nb), dim3(256), 0, c->stream, n, a, x, y);
+    HIP_TRY(hipGetLastError());
+    return EDRGP_OK;
+}
+
+// ----------------------------------------------------------------- indices
+enum {  // c->mats
+    MAT_LM = 0,   // Kmm + jitter, overwritten by its Cholesky factor
+    MAT_LI,       // Lm^-1
+    MAT_PHI,      // [Phi | b]  (M*M + M)
+    MAT_T,        // scratch
+    MAT_A,        // beta Lm^-1 Phi Lm^-T
+    MAT_LB,       // I + A, overwritten by its Cholesky factor
+    MAT_LBI,      // LB^-1
+    MAT_R,        // LB^-1 Lm^-1
+    MAT_P,        // R^T R
+    MAT_KMMI,     // Lm^-T Lm^-1
+    MAT_S2,       // 2 dL/dpsi2
+    MAT_C1,       // scratch
+    MAT_DKMM,     // dL/dKmm
+    MAT_TMM,      // element-wise factor for the Kmm term
+};
+
+enum {  // device scalar slots (c->scal)
+    SC_TRA = 0, SC_SUMLOGLB, SC_DATAFIT, SC_USQ, SC_LBIFROB, SC_YY,
+    SC_DVAR_NM = 6,          // + part (4)
+    SC_DVAR_MM = 10,         // + part (4)
+    SC_YALPHA = 14, SC_SUMLOGL, SC_ALPHASQ, SC_TRKYI,
+    SC_DIAGMIN = 18, SC_DIAGMAX = 19,
+    SC_COUNT = 32
+};
+
+static KSpec make_kspec(const Ctx* c) {
+    KSpec ks;
+    ks.nparts = c->nparts;
+    ks.D = c->D;
+    for (int p = 0; p < EDRGP_MAX_PARTS; ++p) {
+        ks.kind[p] = (p < c->nparts) ? c->kind[p] : 0;
+        ks.var[p] = (p < c->nparts) ? c->var[p] : 0.0;
+    }
+    ks.invl = c->invl.d();
+    return ks;
+}
+
+static double var_sum(const Ctx* c) {
+    double s = 0.0;
+    for (int p = 0; p < c->nparts; ++p) s += c->var[p];
+    return s;
+}
+
+static int ensure_mats(Ctx* c, int n, int count, size_t extra_first = 0) {
+    for (int i = 0; i < count; ++i) {
+        size_t need = (size_t)n * n * sizeof(double);
+        if (i == MAT_PHI) need += ((size_t)n + 8) * sizeof(double);
+        (void)extra_first;
+        TRY(c->mats[i].reserve(need));
+    }
+    TRY(c->scal.reserve(SC_COUNT * sizeof(double)));
+    TRY(c->info.reserve(4 * sizeof(int)));
+    for (int i = 0; i < 6; ++i) TRY(c->tmpvec[i].reserve((size_t)(n + 8) * sizeof(double)));
+    return EDRGP_OK;
+}
+
+// globals over ranks (N, yy) -- data-dependent only, cached
+struct Globals { double N, yy; };
+static int get_globals(Ctx* c, Globals* g) {
+    g->N = (double)c->N;
+    g->yy = c->yy_local;
+    if (c->comm) {
+        TRY(c->red.reserve(2 * sizeof(double)));
+        double h[2] = {g->N, g->yy};
+        HIP_TRY(hipMemcpyAsync(c->red.d(), h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+        TRY(allreduce_sum(c, c->red.d(), 2));
+        HIP_TRY(hipMemcpyAsync(h, c->red.d(), sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        g->N = h[0];
+        g->yy = h[1];
+    }
+    return EDRGP_OK;
+}
+
+// jitchol's jitter ladder: level -1 = none, level k = mean(diag) * 1e-6 * 10^k
+static double jit_amount(int level, double diag_mean_) {
+    if (level < 0) return 0.0;
+    return diag_mean_ * 1e-6 * std::pow(10.0, (double)level);
+}
+
+struct SparseOut {
+    double lml = 0.0;
+    std::vector<double> dvar, dlen, dZ;
+    double dnoise = 0.0;
+};
+
+// One evaluation of the Titsias bound (VarDTC.inference) with optional
+// gradients / posterior.  Returns EDRGP_ERR_NOT_PD when a factorisation fails
+// at every jitter level.
+static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
+    if (!c->have_data || !c->have_Z || !c->have_kernel) {
+        set_error("sparse evaluation needs set_data, set_inducing and set_kernel first");
+        return EDRGP_ERR_STATE;
+    }
+    const int M = c->M, D = c->D;
+    const int64_t N = c->N;
+    const int Wd = 2 * D + 1;
+    const int np = c->nparts;
+    const double beta = 1.0 / std::max(c->noise_var, 1e-8);
+    const KSpec ks = make_kspec(c);
+    Globals gl;
+    TRY(get_globals(c, &gl));
+
+    TRY(ensure_mats(c, M, need_grad ? 14 : (need_post ? 10 : 7)));
+    const int64_t chunk = std::min<int64_t>(N, std::max<int64_t>(64, c->chunk_rows));
+    const int64_t nchunks = (N + chunk - 1) / chunk;
+    TRY(c->Knm.reserve((size_t)chunk * M * sizeof(double)));
+    double* Lm = c->mats[MAT_LM].d();
+    double* Li = c->mats[MAT_LI].d();
+    double* Phi = c->mats[MAT_PHI].d();
+    double* bvec = Phi + (size_t)M * M;
+    double* Tm = c->mats[MAT_T].d();
+    double* A = c->mats[MAT_A].d();
+    double* LB = c->mats[MAT_LB].d();
+    double* LBi = c->mats[MAT_LBI].d();
+    double* sc = c->scal.d();
+    int* info = static_cast<int*>(c->info.p);
+    double* v_v = c->tmpvec[0].d();
+    double* v_c = c->tmpvec[1].d();
+    double* v_u = c->tmpvec[2].d();
+    double* v_wv = c->tmpvec[3].d();
+    double* v_tmp = c->tmpvec[4].d();
+
+    double h_sc[SC_COUNT];
+    int h_info[4];
+
+    // ---- phase 1: Kmm + (1e-8 + jitter) I, Lm (jitchol ladder), Lm^-1
+    const double kmm_diag_mean = var_sum(c) + 1e-8;
+    for (int lvl = -1;;) {
+        ProfScope ps(c, EDRGP_PROF_SMALL);
+        TRY(kernel_matrix(c, ks, c->Z.d(), M, c->Z.d(), M, Lm, M, 1, 1e-8 + jit_amount(lvl, kmm_diag_mean),
+                          nullptr, nullptr));
+        TRY(potrf_lower(c, Lm, M, M, info + 0));
+        TRY(diag_minmax(c, Lm, M, M, sc + SC_DIAGMIN));
+        HIP_TRY(hipMemcpyAsync(h_sc, sc, sizeof(h_sc), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(h_info, info, sizeof(h_info), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (h_info[0] == 0) break;
+        if (++lvl > 4) { set_error("Kmm not positive definite, even with jitter"); return EDRGP_ERR_NOT_PD; }
+    }
+    TRY(trtri_lower(c, Lm, M, Li, M, M));
+    // Pivot-ratio proxy of cond(Kmm).  The Gram form A = beta Li (K^T K) Li^T loses
+    // accuracy ~ eps * cond(Kmm); beyond the threshold switch to the GPy-ordered
+    // form A = beta (K Li^T)^T (K Li^T), whose error grows with sqrt(cond) only.
+    const double pr = h_sc[SC_DIAGMAX] / h_sc[SC_DIAGMIN];
+    const bool stable = (c->stats_mode == 2) || (c->stats_mode == 0 && pr * pr > c->pivot_ratio_max);
+    c->last_mode = stable ? 2 : 1;
+
+    // ---- phase 2: row statistics.  gram: Phi = K^T K, b = K^T y.
+    //      stable: Phi := (K Li^T)^T (K Li^T), b := (K Li^T)^T y  (= Li b)
+    bool k_resident = false;
+    if (stable) TRY(c->W.reserve((size_t)chunk * M * sizeof(double)));
+    for (int64_t ch = 0; ch < nchunks; ++ch) {
+        const int64_t r0 = ch * chunk;
+        const int64_t rows = std::min<int64_t>(chunk, N - r0);
+        double* btarget = (ch == 0) ? bvec : v_tmp;
+        {
+            ProfScope ps(c, EDRGP_PROF_KBUILD);
+            TRY(kernel_matrix(c, ks, c->X.d() + (size_t)r0 * D, rows, c->Z.d(), M, c->Knm.d(), M, 0, 0.0,
+                              stable ? nullptr : c->y.d() + r0, stable ? nullptr : btarget));
+        }
+        const double* S = c->Knm.d();
+        if (stable) {
+            ProfScope ps(c, EDRGP_PROF_GRADGEMM);
+            GemmOpts o;
+            o.tag = 2;
+            TRY(gemm(c, false, true, (int)rows, M, M, 1.0, c->Knm.d(), M, Li, M, 0.0, c->W.d(), M, o));
+            TRY(gemv_t(c, (int)rows, M, 1.0, c->W.d(), M, c->y.d() + r0, btarget));
+            S = c->W.d();
+        }
+        if (ch > 0) TRY(vec_axpy(c, M, 1.0, v_tmp, bvec));
+        TRY(syrk_tn(c, S, rows, M, M, Phi, M, ch > 0));
+    }
+    k_resident = (nchunks == 1);
+    if (c->comm) TRY(allreduce_sum(c, Phi, (size_t)M * M + M));
+
+    // ---- phase 3: A, B = I + A (jitchol ladder), LB^-1, the M-vectors and scalars
+    for (int lvl = -1;;) {
+        ProfScope ps(c, EDRGP_PROF_SMALL);
+        HIP_TRY(hipMemsetAsync(sc, 0, SC_COUNT * sizeof(double), c->stream));
+        if (stable) {
+            TRY(combine3(c, M, beta, Phi, 0.0, nullptr, 0.0, nullptr, 0.0, nullptr, A));
+            HIP_TRY(hipMemcpyAsync(v_v, bvec, (size_t)M * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        } else {
+            TRY(gemm(c, false, false, M, M, M, 1.0, Li, M, Phi, M, 0.0, Tm, M));
+            TRY(gemm(c, false, true, M, M, M, beta, Tm, M, Li, M, 0.0, A, M));
+            TRY(gemv_n(c, M, M, 1.0, Li, M, bvec, v_v));
+        }
+        TRY(trace_of(c, A, M, M, sc + SC_TRA));
+        HIP_TRY(hipMemcpyAsync(LB, A, (size_t)M * M * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        // jitter on B: mean(diag(B)) = 1 + trA / M, trA known from the failed pass
+        TRY(add_diag(c, LB, M, M, 1.0 + (lvl >= 0 ? jit_amount(lvl, 1.0 + h_sc[SC_TRA] / M) : 0.0)));
+        TRY(potrf_lower(c, LB, M, M, info + 1));
+        TRY(trtri_lower(c, LB, M, LBi, M, M));
+        TRY(sum_log_diag(c, LB, M, M, sc + SC_SUMLOGLB));
+        // c = beta LBi v ; u = LBi^T c ; wv = Li^T u     (v = Lm^-1 K_mn y)
+        TRY(gemv_n(c, M, M, beta, LBi, M, v_v, v_c));
+        TRY(gemv_t(c, M, M, 1.0, LBi, M, v_c, v_u));
+        TRY(gemv_t(c, M, M, 1.0, Li, M, v_u, v_wv));
+        TRY(sum_sq(c, v_c, M, sc + SC_DATAFIT));
+        TRY(sum_sq(c, v_u, M, sc + SC_USQ));
+        TRY(frob_sq(c, LBi, M, M, sc + SC_LBIFROB));
+        HIP_TRY(hipMemcpyAsync(h_sc, sc, sizeof(h_sc), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(h_info, info, sizeof(h_info), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (h_info[1] == 0) break;
+        if (++lvl > 4) { set_error("I + A not positive definite, even with jitter"); return EDRGP_ERR_NOT_PD; }
+    }
+    c->drain_events();
+
+    const double psi0sum = gl.N * var_sum(c);
+    const double trA = h_sc[SC_TRA], data_fit = h_sc[SC_DATAFIT];
+    out->lml = -0.5 * gl.N * (std::log(2.0 * M_PI) - std::log(beta)) - 0.5 * beta * gl.yy -
+               0.5 * (beta * psi0sum - trA) - h_sc[SC_SUMLOGLB] + 0.5 * data_fit;
+    if (!need_grad && !need_post) return EDRGP_OK;
+
+    double* R = c->mats[MAT_R].d();
+    double* P = c->mats[MAT_P].d();
+    double* Kmmi = c->mats[MAT_KMMI].d();
+    {
+        ProfScope ps(c, EDRGP_PROF_SMALL);
+        TRY(gemm(c, false, false, M, M, M, 1.0, LBi, M, Li, M, 0.0, R, M));
+        TRY(gemm(c, true, false, M, M, M, 1.0, R, M, R, M, 0.0, P, M));
+        TRY(gemm(c, true, false, M, M, M, 1.0, Li, M, Li, M, 0.0, Kmmi, M));
+    }
+    if (need_post) {
+        TRY(c->wv.reserve((size_t)M * sizeof(double)));
+        TRY(c->winv.reserve((size_t)M * M * sizeof(double)));
+        HIP_TRY(hipMemcpyAsync(c->wv.d(), v_wv, (size_t)M * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        TRY(combine3(c, M, 1.0, Kmmi, -1.0, P, 0.0, nullptr, 0.0, nullptr, c->winv.d()));
+        c->have_post = true;
+        c->post_dense = false;
+        c->P = M;
+    }
+    if (!need_grad) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->drain_events();
+        return EDRGP_OK;
+    }
+
+    // ---- gradients: SparseGP._update_gradients
+    double* S2 = c->mats[MAT_S2].d();
+    double* C1 = c->mats[MAT_C1].d();
+    double* dKmm = c->mats[MAT_DKMM].d();
+    double* Tmm = c->mats[MAT_TMM].d();
+    {
+        ProfScope ps(c, EDRGP_PROF_SMALL);
+        // S2 = 2 dL/dpsi2 = beta (Kmm^-1 - P - wv wv^T)
+        TRY(combine3(c, M, beta, Kmmi, -beta, P, 0.0, nullptr, -beta, v_wv, S2));
+        // C1 = Li^T A ; Tm = C1 Li = Lm^-T A Lm^-1
+        TRY(gemm(c, true, false, M, M, M, 1.0, Li, M, A, M, 0.0, C1, M));
+        TRY(gemm(c, false, false, M, M, M, 1.0, C1, M, Li, M, 0.0, Tm, M));
+        // dL/dKmm = 1/2 Kmm^-1 - 1/2 P - 1/2 wv wv^T - 1/2 Lm^-T A Lm^-1
+        TRY(combine3(c, M, 0.5, Kmmi, -0.5, P, -0.5, Tm, -0.5, v_wv, dKmm));
+    }
+    TRY(c->W.reserve((size_t)chunk * M * sizeof(double)));
+    TRY(c->T.reserve((size_t)chunk * M * sizeof(double)));
+    TRY(c->gt_nm.reserve((size_t)np * M * Wd * sizeof(double)));
+    TRY(c->gt_mm.reserve((size_t)2 * np * M * Wd * sizeof(double)));
+    for (int64_t ch = 0; ch < nchunks; ++ch) {
+        const int64_t r0 = ch * chunk;
+        const int64_t rows = std::min<int64_t>(chunk, N - r0);
+        if (!k_resident) {
+            ProfScope ps(c, EDRGP_PROF_KBUILD);
+            TRY(kernel_matrix(c, ks, c->X.d() + (size_t)r0 * D, rows, c->Z.d(), M, c->Knm.d(), M, 0, 0.0, nullptr,
+                              nullptr));
+        }
+        {
+            ProfScope ps(c, EDRGP_PROF_GRADGEMM);
+            GemmOpts o;
+            o.tag = 2;
+            TRY(gemm(c, false, false, (int)rows, M, M, 1.0, c->Knm.d(), M, S2, M, 0.0, c->W.d(), M, o));
+        }
+        for (int p = 0; p < np; ++p) {
+            TRY(grad_elementwise(c, ks, p, c->X.d() + (size_t)r0 * D, c->y.d() + r0, rows, c->Z.d(), M, c->W.d(), M,
+                                 beta, v_wv, c->T.d(), M, sc + SC_DVAR_NM + p));
+            TRY(gemm(c, true, false, M, Wd, (int)rows, 1.0, c->T.d(), M, c->Xt.d() + (size_t)r0 * Wd, Wd,
+                     ch > 0 ? 1.0 : 0.0, c->gt_nm.d() + (size_t)p * M * Wd, Wd));
+        }
+    }
+    // Kmm term (X2 = None upstream): element-wise factor of dL/dKmm, then T^T Zt and T Zt
+    for (int p = 0; p < np; ++p) {
+        TRY(grad_elementwise(c, ks, p, c->Z.d(), nullptr, M, c->Z.d(), M, dKmm, M, 0.0, nullptr, Tmm, M,
+                             sc + SC_DVAR_MM + p));
+        TRY(gemm(c, true, false, M, Wd, M, 1.0, Tmm, M, c->Zt.d(), Wd, 0.0,
+                 c->gt_mm.d() + (size_t)(2 * p) * M * Wd, Wd));
+        TRY(gemm(c, false, false, M, Wd, M, 1.0, Tmm, M, c->Zt.d(), Wd, 0.0,
+                 c->gt_mm.d() + (size_t)(2 * p + 1) * M * Wd, Wd));
+    }
+    if (c->comm) {
+        TRY(allreduce_sum(c, c->gt_nm.d(), (size_t)np * M * Wd));
+        TRY(allreduce_sum(c, sc + SC_DVAR_NM, EDRGP_MAX_PARTS));
+    }
+    std::vector<double> g_nm((size_t)np * M * Wd), g_mm((size_t)2 * np * M * Wd), Zh((size_t)M * D);
+    HIP_TRY(hipMemcpyAsync(h_sc, sc, sizeof(h_sc), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(g_nm.data(), c->gt_nm.d(), g_nm.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(g_mm.data(), c->gt_mm.d(), g_mm.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(Zh.data(), c->Z.d(), Zh.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->drain_events();
+
+    // ---- finishing on the host: O(M D) arithmetic
+    out->dvar.assign(np, 0.0);
+    out->dlen.assign((size_t)np * D, 0.0);
+    out->dZ.assign((size_t)M * D, 0.0);
+    for (int p = 0; p < np; ++p) {
+        out->dvar[p] = h_sc[SC_DVAR_NM + p] + h_sc[SC_DVAR_MM + p] - 0.5 * beta * gl.N;   // + sum dL_dKdiag
+        const double* Gn = &g_nm[(size_t)p * M * Wd];
+        const double* GmT = &g_mm[(size_t)(2 * p) * M * Wd];
+        const double* GmN = &g_mm[(size_t)(2 * p + 1) * M * Wd];
+        for (int q = 0; q < D; ++q) {
+            const double l = c->lens[(size_t)p * D + q];
+            const double il2 = 1.0 / (l * l), il3 = il2 / l;
+            double s_nm = 0.0, s_mm = 0.0;
+            for (int m = 0; m < M; ++m) {
+                const double z = Zh[(size_t)m * D + q];
+                const double* gn = Gn + (size_t)m * Wd;
+                const double* gt = GmT + (size_t)m * Wd;
+                const double* gN = GmN + (size_t)m * Wd;
+                s_nm += gn[D + 1 + q] + gn[D] * z * z - 2.0 * z * gn[q];
+                s_mm += gt[D + 1 + q] + gt[D] * z * z - 2.0 * z * gt[q];
+                out->dZ[(size_t)m * D + q] +=
+                    il2 * ((z * gn[D] - gn[q]) + (z * gt[D] - gt[q]) + (z * gN[D] - gN[q]));
+            }
+            out->dlen[(size_t)p * D + q] = -il3 * (s_nm + s_mm);
+        }
+    }
+    {
+        // _compute_dL_dR (homoscedastic); sum(A .* DBi_plus_BiPBi) = M - |LBi|_F^2 + |c|^2 - |u|^2
+        const double sumA_DBi = (double)M - h_sc[SC_LBIFROB] + data_fit - h_sc[SC_USQ];
+        double dR = -0.5 * gl.N * beta + 0.5 * gl.yy * beta * beta;
+        dR += 0.5 * (psi0sum * beta * beta - trA * beta);
+        dR += beta * (0.5 * sumA_DBi - data_fit);
+        out->dnoise = dR;
+    }
+    return EDRGP_OK;
+}
+
+struct DenseOut {
+    double lml = 0.0;
+    std::vector<double> dvar, dlen;
+    double dnoise = 0.0;
+};
+
+// ExactGaussianInference.inference on the resident (X, y).
+static int dense_eval(Ctx* c, bool need_grad, bool need_post, DenseOut* out) {
+    if (!c->have_data || !c->have_kernel) {
+        set_error("dense evaluation needs set_data and set_kernel first");
+        return EDRGP_ERR_STATE;
+    }
+    if (c->comm) { set_error("the dense exact GP does not shard: replicas only"); return EDRGP_ERR_STATE; }
+    if (c->N > 46000) { set_error("dense exact GP limited to N <= 46000"); return EDRGP_ERR_INVALID; }
+    const int n = (int)c->N, D = c->D, np = c->nparts, Wd = 2 * D + 1;
+    const KSpec ks = make_kspec(c);
+    TRY(ensure_mats(c, n, need_grad ? 5 : 3));
+    double* L = c->mats[0].d();
+    double* Li = c->mats[1].d();
+    double* Kyi = c->mats[2].d();
+    double* dK = c->mats[3].d();
+    double* Tn = c->mats[4].d();
+    double* sc = c->scal.d();
+    int* info = static_cast<int*>(c->info.p);
+    double* alpha = c->tmpvec[0].d();
+    const double diag_mean_ = var_sum(c) + c->noise_var + 1e-8;
+    int lvl = -1;
+    double h_sc[SC_COUNT];
+    int h_info[4];
+    for (;;) {
+        ProfScope ps(c, EDRGP_PROF_SMALL);
+        HIP_TRY(hipMemsetAsync(sc, 0, SC_COUNT * sizeof(double), c->stream));
+        TRY(kernel_matrix(c, ks, c->X.d(), n, c->X.d(), n, L, n, 1,
+                          c->noise_var + 1e-8 + jit_amount(lvl, diag_mean_), nullptr, nullptr));
+        TRY(potrf_lower(c, L, n, n, info));
+        TRY(trtri_lower(c, L, n, Li, n, n));
+        TRY(gemm(c, true, false, n, n, n, 1.0, Li, n, Li, n, 0.0, Kyi, n));
+        TRY(gemv_n(c, n, n, 1.0, Kyi, n, c->y.d(), alpha));
+        TRY(sum_log_diag(c, L, n, n, sc + SC_SUMLOGL));
+        TRY(dot(c, c->y.d(), alpha, n, sc + SC_YALPHA));
+        TRY(sum_sq(c, alpha, n, sc + SC_ALPHASQ));
+        TRY(trace_of(c, Kyi, n, n, sc + SC_TRKYI));
+        HIP_TRY(hipMemcpyAsync(h_sc, sc, sizeof(h_sc), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(h_info, info, sizeof(h_info), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (h_info[0] != 0) {
+            if (++lvl > 4) { set_error("K + noise not positive definite, even with jitter"); return EDRGP_ERR_NOT_PD; }
+            continue;
+        }
+        break;
+    }
+    c->drain_events();
+    out->lml = 0.5 * (-(double)n * std::log(2.0 * M_PI) - 2.0 * h_sc[SC_SUMLOGL] - h_sc[SC_YALPHA]);
+    if (need_post) {
+        TRY(c->wv.reserve((size_t)n * sizeof(double)));
+        TRY(c->winv.reserve((size_t)n * n * sizeof(double)));
+        HIP_TRY(hipMemcpyAsync(c->wv.d(), alpha, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->winv.d(), Kyi, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        c->have_post = true;
+        c->post_dense = true;
+        c->P = n;
+    }
+    if (!need_grad) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return EDRGP_OK;
+    }
+    // dL/dK = 1/2 (alpha alpha^T - Ky^-1)
+    TRY(combine3(c, n, -0.5, Kyi, 0.0, nullptr, 0.0, nullptr, 0.5, alpha, dK));
+    TRY(c->gt_nm.reserve((size_t)np * n * Wd * sizeof(double)));
+    for (int p = 0; p < np; ++p) {
+        TRY(grad_elementwise(c, ks, p, c->X.d(), nullptr, n, c->X.d(), n, dK, n, 0.0, nullptr, Tn, n,
+                             sc + SC_DVAR_NM + p));
+        TRY(gemm(c, true, false, n, Wd, n, 1.0, Tn, n, c->Xt.d(), Wd, 0.0, c->gt_nm.d() + (size_t)p * n * Wd, Wd));
+    }
+    std::vector<double> g((size_t)np * n * Wd), Xh((size_t)n * D);
+    HIP_TRY(hipMemcpyAsync(h_sc, sc, sizeof(h_sc), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(g.data(), c->gt_nm.d(), g.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(Xh.data(), c->X.d(), Xh.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    out->dvar.assign(np, 0.0);
+    out->dlen.assign((size_t)np * D, 0.0);
+    for (int p = 0; p < np; ++p) {
+        out->dvar[p] = h_sc[SC_DVAR_NM + p];
+        const double* G = &g[(size_t)p * n * Wd];
+        for (int q = 0; q < D; ++q) {
+            const double l = c->lens[(size_t)p * D + q];
+            const double il3 = 1.0 / (l * l * l);
+            double s = 0.0;
+            for (int m = 0; m < n; ++m) {
+                const double x = Xh[(size_t)m * D + q];
+                const double* gm = G + (size_t)m * Wd;
+                s += gm[D + 1 + q] + gm[D] * x * x - 2.0 * x * gm[q];
+            }
+            out->dlen[(size_t)p * D + q] = -il3 * s;
+        }
+    }
+    out->dnoise = 0.5 * (h_sc[SC_ALPHASQ] - h_sc[SC_TRKYI]);
+    return EDRGP_OK;
+}
+
+// Prediction on a device-resident block of inputs; outputs to host pointers.
+static int predict_rows(Ctx* c, const double* Xs_dev, int64_t Ns, double* mean_h, double* var_h, double* jac_h) {
+    if (!c->have_post) { set_error("no posterior: call *_posterior first"); return EDRGP_ERR_STATE; }
+    const int D = c->D, Mp = c->P, Wd = 2 * D + 1;
+    const KSpec ks = make_kspec(c);
+    const double* Pp = c->post_dense ? c->X.d() : c->Z.d();
+    const double* Pt = c->post_dense ? c->Xt.d() : c->Zt.d();
+    int64_t chunk = std::max<int64_t>(64, std::min<int64_t>(c->chunk_rows, (int64_t)(1LL << 28) / std::max(1, Mp)));
+    chunk = std::min<int64_t>(chunk, Ns);
+    TRY(c->Knm.reserve((size_t)chunk * Mp * sizeof(double)));
+    TRY(c->W.reserve((size_t)chunk * Mp * sizeof(double)));
+    TRY(c->T.reserve((size_t)chunk * (Wd + D + 2) * sizeof(double)));
+    double* GT = c->T.d();
+    double* o_jac = GT + (size_t)chunk * Wd;
+    double* o_mean = o_jac + (size_t)chunk * D;
+    double* o_var = o_mean + chunk;
+    const double kdiag = var_sum(c);
+    for (int64_t r0 = 0; r0 < Ns; r0 += chunk) {
+        const int64_t rows = std::min<int64_t>(chunk, Ns - r0);
+        TRY(predict_chunk(c, ks, Xs_dev + (size_t)r0 * D, rows, Pp, Pt, Mp, c->wv.d(), c->winv.d(), kdiag,
+                          c->Knm.d(), c->W.d(), GT, mean_h ? o_mean : nullptr, var_h ? o_var : nullptr,
+                          jac_h ? o_jac : nullptr));
+        if (mean_h) HIP_TRY(hipMemcpyAsync(mean_h + r0, o_mean, rows * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (var_h) HIP_TRY(hipMemcpyAsync(var_h + r0, o_var, rows * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (jac_h)
+            HIP_TRY(hipMemcpyAsync(jac_h + (size_t)r0 * D, o_jac, (size_t)rows * D * sizeof(double),
+                                   hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return EDRGP_OK;
+}
+
+}  // namespace edrgp
+
+// ===========================================================================
+using namespace edrgp;
+
+extern "C" {
+
+const char* edrgp_last_error(void) { return g_err.c_str(); }
+int edrgp_version(void) { return 100; }
+
+int edrgp_device_count(int* count) {
+    if (!count) return EDRGP_ERR_INVALID;
+    HIP_TRY(hipGetDeviceCount(count));
+    return EDRGP_OK;
+}
+
+int edrgp_ctx_create(int device, edrgp_ctx** ctx) {
+    if (!ctx) return EDRGP_ERR_INVALID;
+    *ctx = nullptr;
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (n <= 0 || device < 0 || device >= n) {
+        set_error("no HIP device %d (device count %d): the MI355X path has no CPU fallback", device, n);
+        return EDRGP_ERR_HIP;
+    }
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+        return EDRGP_ERR_HIP;
+    }
+    Ctx* c = new Ctx();
+    c->device = device;
+    c->num_cu = prop.multiProcessorCount;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    *ctx = reinterpret_cast<edrgp_ctx*>(c);
+    return EDRGP_OK;
+}
+
+int edrgp_ctx_destroy(edrgp_ctx* ctx) {
+    if (!ctx) return EDRGP_OK;
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->drain_events();
+    if (c->comm) edrgp_comm_destroy(ctx);
+    DBuf* bufs[] = {&c->X, &c->y, &c->Z, &c->Xt, &c->Zt, &c->invl, &c->wv, &c->winv, &c->Knm, &c->W, &c->T, &c->slabs,
+                    &c->bpart, &c->scal, &c->info, &c->gt_nm, &c->gt_mm, &c->panel, &c->trtri_ws, &c->dinv, &c->red};
+    for (DBuf* b : bufs) b->release();
+    for (auto& m : c->mats) m.release();
+    for (auto& v : c->tmpvec) v.release();
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return EDRGP_OK;
+}
+
+#define CTX(ctx)                                                   \
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);                          \
+    if (!c) { set_error("null context"); return EDRGP_ERR_INVALID; } \
+    HIP_TRY(hipSetDevice(c->device))
+
+int edrgp_sync(edrgp_ctx* ctx) {
+    CTX(ctx);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->drain_events();
+    return EDRGP_OK;
+}
+
+int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
+    CTX(ctx);
+    if (!key) return EDRGP_ERR_INVALID;
+    if (!std::strcmp(key, "chunk_rows")) c->chunk_rows = std::max<int64_t>(64, (int64_t)value);
+    else if (!std::strcmp(key, "syrk_splits")) c->syrk_splits = (int)value;
+    else if (!std::strcmp(key, "profile")) c->profile = (value != 0.0);
+    else if (!std::strcmp(key, "stats_mode")) c->stats_mode = (int)value;          // 0 auto, 1 gram, 2 stable
+    else if (!std::strcmp(key, "pivot_ratio_max")) c->pivot_ratio_max = value;
+    else { set_error("unknown option %s", key); return EDRGP_ERR_INVALID; }
+    return EDRGP_OK;
+}
+
+int edrgp_set_data(edrgp_ctx* ctx, const double* X, const double* y, int64_t N, int D) {
+    CTX(ctx);
+    if (!X || !y || N <= 0 || D <= 0 || D > EDRGP_MAX_DIM) { set_error("set_data: bad shape N=%lld D=%d", (long long)N, D); return EDRGP_ERR_INVALID; }
+    if (c->have_Z && c->D != D) c->have_Z = false;
+    if (c->have_kernel && c->D != D) c->have_kernel = false;
+    c->have_post = false;
+    TRY(c->X.reserve((size_t)N * D * sizeof(double)));
+    TRY(c->y.reserve((size_t)N * sizeof(double)));
+    TRY(c->Xt.reserve((size_t)N * (2 * D + 1) * sizeof(double)));
+    TRY(c->scal.reserve(SC_COUNT * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(c->X.d(), X, (size_t)N * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->y.d(), y, (size_t)N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    c->N = N;
+    c->D = D;
+    TRY(build_xtilde(c, c->X.d(), N, D, c->Xt.d()));
+    TRY(sum_sq(c, c->y.d(), N, c->scal.d() + SC_YY));
+    double yy = 0.0;
+    HIP_TRY(hipMemcpyAsync(&yy, c->scal.d() + SC_YY, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->yy_local = yy;
+    c->have_data = true;
+    return EDRGP_OK;
+}
+
+int edrgp_set_inducing(edrgp_ctx* ctx, const double* Z, int M) {
+    CTX(ctx);
+    if (!Z || M <= 0) { set_error("set_inducing: bad M=%d", M); return EDRGP_ERR_INVALID; }
+    if (!c->have_data) { set_error("set_inducing: call set_data first (fixes D)"); return EDRGP_ERR_STATE; }
+    const int D = c->D;
+    TRY(c->Z.reserve((size_t)M * D * sizeof(double)));
+    TRY(c->Zt.reserve((size_t)M * (2 * D + 1) * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(c->Z.d(), Z, (size_t)M * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    TRY(build_xtilde(c, c->Z.d(), M, D, c->Zt.d()));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // Z is a borrowed host pointer
+    c->M = M;
+    c->have_Z = true;
+    if (!c->post_dense) c->have_post = false;
+    return EDRGP_OK;
+}
+
+int edrgp_set_kernel(edrgp_ctx* ctx, int nparts, const int* kinds, const double* variances,
+                     const double* lengthscales, double noise_var) {
+    CTX(ctx);
+    if (!c->have_data) { set_error("set_kernel: call set_data first (fixes D)"); return EDRGP_ERR_STATE; }
+    if (nparts < 1 || nparts > EDRGP_MAX_PARTS || !kinds || !variances || !lengthscales) {
+        set_error("set_kernel: nparts must be 1..%d", EDRGP_MAX_PARTS);
+        return EDRGP_ERR_INVALID;
+    }
+    const int D = c->D;
+    std::vector<double> invl((size_t)nparts * D);
+    for (int p = 0; p < nparts; ++p) {
+        if (kinds[p] < 0 || kinds[p] > 2) { set_error("set_kernel: unknown kind %d", kinds[p]); return EDRGP_ERR_INVALID; }
+        if (!(variances[p] > 0.0)) { set_error("set_kernel: variance must be positive"); return EDRGP_ERR_INVALID; }
+        for (int q = 0; q < D; ++q) {
+            const double l = lengthscales[(size_t)p * D + q];
+            if (!(l > 0.0)) { set_error("set_kernel: lengthscale must be positive"); return EDRGP_ERR_INVALID; }
+            invl[(size_t)p * D + q] = 1.0 / l;
+        }
+    }
+    if (!(noise_var >= 0.0)) { set_error("set_kernel: noise variance must be non-negative"); return EDRGP_ERR_INVALID; }
+    c->nparts = nparts;
+    for (int p = 0; p < nparts; ++p) { c->kind[p] = kinds[p]; c->var[p] = variances[p]; }
+    c->lens.assign(lengthscales, lengthscales + (size_t)nparts * D);
+    c->noise_var = noise_var;
+    TRY(c->invl.reserve((size_t)EDRGP_MAX_PARTS * EDRGP_MAX_DIM * sizeof(double)));
+    // synchronous copy: the staging vector dies at return, and kernels queued
+    // earlier on the stream may still read the previous values
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(c->invl.d(), invl.data(), invl.size() * sizeof(double), hipMemcpyHostToDevice));
+    c->have_kernel = true;
+    c->have_post = false;
+    return EDRGP_OK;
+}
+
+int edrgp_sparse_lml(edrgp_ctx* ctx, double* lml) {
+    CTX(ctx);
+    SparseOut o;
+    TRY(sparse_eval(c, false, false, &o));
+    if (lml) *lml = o.lml;
+    return EDRGP_OK;
+}
+
+int edrgp_sparse_lml_grad(edrgp_ctx* ctx, double* lml, double* dvar, double* dlen, double* dnoise, double* dZ) {
+    CTX(ctx);
+    SparseOut o;
+    TRY(sparse_eval(c, true, false, &o));
+    if (lml) *lml = o.lml;
+    if (dvar) std::memcpy(dvar, o.dvar.data(), o.dvar.size() * sizeof(double));
+    if (dlen) std::memcpy(dlen, o.dlen.data(), o.dlen.size() * sizeof(double));
+    if (dnoise) *dnoise = o.dnoise;
+    if (dZ) std::memcpy(dZ, o.dZ.data(), o.dZ.size() * sizeof(double));
+    return EDRGP_OK;
+}
+
+int edrgp_sparse_posterior(edrgp_ctx* ctx, double* lml) {
+    CTX(ctx);
+    SparseOut o;
+    TRY(sparse_eval(c, false, true, &o));
+    if (lml) *lml = o.lml;
+    return EDRGP_OK;
+}
+
+int edrgp_dense_lml_grad(edrgp_ctx* ctx, double* lml, double* dvar, double* dlen, double* dnoise) {
+    CTX(ctx);
+    DenseOut o;
+    const bool need_grad = (dvar || dlen || dnoise);
+    TRY(dense_eval(c, need_grad, false, &o));
+    if (lml) *lml = o.lml;
+    if (need_grad) {
+        if (dvar) std::memcpy(dvar, o.dvar.data(), o.dvar.size() * sizeof(double));
+        if (dlen) std::memcpy(dlen, o.dlen.data(), o.dlen.size() * sizeof(double));
+        if (dnoise) *dnoise = o.dnoise;
+    }
+    return EDRGP_OK;
+}
+
+int edrgp_dense_posterior(edrgp_ctx* ctx, double* lml) {
+    CTX(ctx);
+    DenseOut o;
+    TRY(dense_eval(c, false, true, &o));
+    if (lml) *lml = o.lml;
+    return EDRGP_OK;
+}
+
+int edrgp_predict(edrgp_ctx* ctx, const double* Xs, int64_t Ns, double* mean, double* var) {
+    CTX(ctx);
+    if (!Xs || Ns <= 0) { set_error("predict: bad input"); return EDRGP_ERR_INVALID; }
+    DBuf xs;
+    TRY(xs.reserve((size_t)Ns * c->D * sizeof(double)));
+    hipError_t e = hipMemcpyAsync(xs.d(), Xs, (size_t)Ns * c->D * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    int s = (e == hipSuccess) ? predict_rows(c, xs.d(), Ns, mean, var, nullptr) : EDRGP_ERR_HIP;
+    (void)hipStreamSynchronize(c->stream);
+    xs.release();
+    if (e != hipSuccess) set_error("predict: H2D copy failed: %s", hipGetErrorString(e));
+    return s;
+}
+
+int edrgp_predict_grad(edrgp_ctx* ctx, const double* Xs, int64_t Ns, double* grad) {
+    CTX(ctx);
+    if (!Xs || Ns <= 0 || !grad) { set_error("predict_grad: bad input"); return EDRGP_ERR_INVALID; }
+    DBuf xs;
+    TRY(xs.reserve((size_t)Ns * c->D * sizeof(double)));
+    hipError_t e = hipMemcpyAsync(xs.d(), Xs, (size_t)Ns * c->D * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    int s = (e == hipSuccess) ? predict_rows(c, xs.d(), Ns, nullptr, nullptr, grad) : EDRGP_ERR_HIP;
+    (void)hipStreamSynchronize(c->stream);
+    xs.release();
+    if (e != hipSuccess) set_error("predict_grad: H2D copy failed: %s", hipGetErrorString(e));
+    return s;
+}
+
+int edrgp_predict_train(edrgp_ctx* ctx, double* mean, double* grad) {
+    CTX(ctx);
+    if (!c->have_data) { set_error("predict_train: no data"); return EDRGP_ERR_STATE; }
+    return predict_rows(c, c->X.d(), c->N, mean, nullptr, grad);
+}
+
+int edrgp_get(edrgp_ctx* ctx, int which, double* buf, int64_t cap) {
+    CTX(ctx);
+    if (!buf) return EDRGP_ERR_INVALID;
+    const size_t M = (size_t)c->M;
+    const double* src = nullptr;
+    size_t n = 0;
+    switch (which) {
+        case EDRGP_GET_PHI: src = c->mats[MAT_PHI].d(); n = M * M; break;
+        case EDRGP_GET_BVEC: src = c->mats[MAT_PHI].d() ? c->mats[MAT_PHI].d() + M * M : nullptr; n = M; break;
+        case EDRGP_GET_LM: case EDRGP_GET_KMM: src = c->mats[MAT_LM].d(); n = M * M; break;
+        case EDRGP_GET_LB: src = c->mats[MAT_LB].d(); n = M * M; break;
+        case EDRGP_GET_A: src = c->mats[MAT_A].d(); n = M * M; break;
+        case EDRGP_GET_WV: src = c->wv.d(); n = (size_t)c->P; break;
+        case EDRGP_GET_WINV: src = c->winv.d(); n = (size_t)c->P * c->P; break;
+        case EDRGP_GET_KNM: src = c->Knm.d(); n = (size_t)std::min<int64_t>(c->N, c->chunk_rows) * M; break;
+        case EDRGP_GET_LMI: src = c->mats[MAT_LI].d(); n = M * M; break;
+        case EDRGP_GET_LBI: src = c->mats[MAT_LBI].d(); n = M * M; break;
+        case EDRGP_GET_DLDKMM: src = c->mats[MAT_DKMM].d(); n = M * M; break;
+        case EDRGP_GET_SCALARS: src = c->scal.d(); n = 16; break;
+        case EDRGP_GET_MODE: buf[0] = (double)c->last_mode; return EDRGP_OK;
+        default: set_error("edrgp_get: unknown selector %d", which); return EDRGP_ERR_INVALID;
+    }
+    if (!src) { set_error("edrgp_get: object %d not computed yet", which); return EDRGP_ERR_STATE; }
+    if ((int64_t)n > cap) { set_error("edrgp_get: buffer too small (%lld < %zu)", (long long)cap, n); return EDRGP_ERR_INVALID; }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(buf, src, n * sizeof(double), hipMemcpyDeviceToHost));
+    return EDRGP_OK;
+}
+
+int edrgp_profile_reset(edrgp_ctx* ctx) {
+    CTX(ctx);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->drain_events();
+    for (auto& p : c->prof) p = ProfSlot();
+    return EDRGP_OK;
+}
+
+int edrgp_profile_get(edrgp_ctx* ctx, int slot, double* total_ms, int64_t* launches) {
+    CTX(ctx);
+    if (slot < 0 || slot >= EDRGP_PROF_NSLOTS) return EDRGP_ERR_INVALID;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->drain_events();
+    if (total_ms) *total_ms = c->prof[slot].total_ms;
+    if (launches) *launches = c->prof[slot].launches;
+    return EDRGP_OK;
+}
+
+// ------------------------------------------------------------- debug hooks
+int edrgp_dbg_gemm(edrgp_ctx* ctx, int transA, int transB, int M, int N, int K, double alpha, const double* A,
+                   int lda, const double* B, int ldb, double beta, double* C, int ldc) {
+    CTX(ctx);
+    const size_t ra = transA ? K : M, rb = transB ? N : K;
+    DBuf dA, dB, dC;
+    TRY(dA.reserve(ra * lda * sizeof(double)));
+    TRY(dB.reserve(rb * ldb * sizeof(double)));
+    TRY(dC.reserve((size_t)M * ldc * sizeof(double)));
+    HIP_TRY(hipMemcpy(dA.d(), A, ra * lda * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dB.d(), B, rb * ldb * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dC.d(), C, (size_t)M * ldc * sizeof(double), hipMemcpyHostToDevice));
+    int s = gemm(c, transA != 0, transB != 0, M, N, K, alpha, dA.d(), lda, dB.d(), ldb, beta, dC.d(), ldc);
+    if (s == EDRGP_OK && hipStreamSynchronize(c->stream) != hipSuccess) { set_error("dbg_gemm: kernel failed"); s = EDRGP_ERR_HIP; }
+    if (s == EDRGP_OK) HIP_TRY(hipMemcpy(C, dC.d(), (size_t)M * ldc * sizeof(double), hipMemcpyDeviceToHost));
+    dA.release(); dB.release(); dC.release();
+    return s;
+}
+
+int edrgp_dbg_potrf(edrgp_ctx* ctx, double* A, int n, int* info) {
+    CTX(ctx);
+    DBuf dA;
+    TRY(dA.reserve((size_t)n * n * sizeof(double)));
+    TRY(c->info.reserve(4 * sizeof(int)));
+    HIP_TRY(hipMemcpy(dA.d(), A, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice));
+    int s = potrf_lower(c, dA.d(), n, n, static_cast<int*>(c->info.p));
+    if (s == EDRGP_OK && hipStreamSynchronize(c->stream) != hipSuccess) { set_error("dbg_potrf: kernel failed"); s = EDRGP_ERR_HIP; }
+    if (s == EDRGP_OK) {
+        HIP_TRY(hipMemcpy(A, dA.d(), (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost));
+        int h = 0;
+        HIP_TRY(hipMemcpy(&h, c->info.p, sizeof(int), hipMemcpyDeviceToHost));
+        if (info) *info = h;
+    }
+    dA.release();
+    return s;
+}
+
+int edrgp_dbg_trtri(edrgp_ctx* ctx, const double* L, double* Linv, int n) {
+    CTX(ctx);
+    DBuf dL, dI;
+    TRY(dL.reserve((size_t)n * n * sizeof(double)));
+    TRY(dI.reserve((size_t)n * n * sizeof(double)));
+    HIP_TRY(hipMemcpy(dL.d(), L, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice));
+    int s = trtri_lower(c, dL.d(), n, dI.d(), n, n);
+    if (s == EDRGP_OK && hipStreamSynchronize(c->stream) != hipSuccess) { set_error("dbg_trtri: kernel failed"); s = EDRGP_ERR_HIP; }
+    if (s == EDRGP_OK) HIP_TRY(hipMemcpy(Linv, dI.d(), (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost));
+    dL.release(); dI.release();
+    return s;
+}
+
+int edrgp_dbg_syrk(edrgp_ctx* ctx, const double* K, int64_t N, int M, double* Phi) {
+    CTX(ctx);
+    DBuf dK, dP;
+    TRY(dK.reserve((size_t)N * M * sizeof(double)));
+    TRY(dP.reserve((size_t)M * M * sizeof(double)));
+    HIP_TRY(hipMemcpy(dK.d(), K, (size_t)N * M * sizeof(double), hipMemcpyHostToDevice));
+    int s = syrk_tn(c, dK.d(), N, M, M, dP.d(), M, false);
+    if (s == EDRGP_OK && hipStreamSynchronize(c->stream) != hipSuccess) { set_error("dbg_syrk: kernel failed"); s = EDRGP_ERR_HIP; }
+    c->drain_events();
+    if (s == EDRGP_OK) HIP_TRY(hipMemcpy(Phi, dP.d(), (size_t)M * M * sizeof(double), hipMemcpyDeviceToHost));
+    dK.release(); dP.release();
+    return s;
+}
+
+int edrgp_dbg_kernel_matrix(edrgp_ctx* ctx, const double* X, int64_t N, const double* X2, int64_t N2, int D,
+                            double* K) {
+    CTX(ctx);
+    if (!c->have_kernel || D != c->D) { set_error("dbg_kernel_matrix: set_kernel first, D must match"); return EDRGP_ERR_STATE; }
+    const bool same = (X2 == nullptr);
+    const int64_t n2 = same ? N : N2;
+    DBuf dX, dX2, dK;
+    TRY(dX.reserve((size_t)N * D * sizeof(double)));
+    TRY(dK.reserve((size_t)N * n2 * sizeof(double)));
+    HIP_TRY(hipMemcpy(dX.d(), X, (size_t)N * D * sizeof(double), hipMemcpyHostToDevice));
+    if (!same) {
+        TRY(dX2.reserve((size_t)N2 * D * sizeof(double)));
+        HIP_TRY(hipMemcpy(dX2.d(), X2, (size_t)N2 * D * sizeof(double), hipMemcpyHostToDevice));
+    }
+    const KSpec ks = make_kspec(c);
+    int s = kernel_matrix(c, ks, dX.d(), N, same ? dX.d() : dX2.d(), (int)n2, dK.d(), (int)n2, same ? 1 : 0, 0.0,
+                          nullptr, nullptr);
+    if (s == EDRGP_OK && hipStreamSynchronize(c->stream) != hipSuccess) { set_error("dbg_kernel_matrix: kernel failed"); s = EDRGP_ERR_HIP; }
+    if (s == EDRGP_OK) HIP_TRY(hipMemcpy(K, dK.d(), (size_t)N * n2 * sizeof(double), hipMemcpyDeviceToHost));
+    dX.release(); dX2.release(); dK.release();
+    return s;
+}
+
+int edrgp_dbg_mfma_layout(edrgp_ctx* ctx, const double* A16x4, const double* B4x16, double* C16x16) {
+    CTX(ctx);
+    DBuf dA, dB, dC;
+    TRY(dA.reserve(64 * sizeof(double)));
+    TRY(dB.reserve(64 * sizeof(double)));
+    TRY(dC.reserve(256 * sizeof(double)));
+    HIP_TRY(hipMemcpy(dA.d(), A16x4, 64 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dB.d(), B4x16, 64 * sizeof(double), hipMemcpyHostToDevice));
+    int s = mfma_layout_probe(c, dA.d(), dB.d(), dC.d());
+    if (s == EDRGP_OK && hipStreamSynchronize(c->stream) != hipSuccess) s = EDRGP_ERR_HIP;
+    if (s == EDRGP_OK) HIP_TRY(hipMemcpy(C16x16, dC.d(), 256 * sizeof(double), hipMemcpyDeviceToHost));
+    dA.release(); dB.release(); dC.release();
+    return s;
+}
+
+int edrgp_calib(edrgp_ctx* ctx, double* mfma_f64_tflops, double* hbm_copy_gbps) {
+    CTX(ctx);
+    if (mfma_f64_tflops) TRY(calib_mfma_f64(c, mfma_f64_tflops));
+    if (hbm_copy_gbps) TRY(calib_hbm_copy(c, hbm_copy_gbps));
+    return EDRGP_OK;
+}
+
+}  // extern "C"

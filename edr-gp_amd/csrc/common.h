@@ -1,0 +1,189 @@
+// Internal declarations shared by the HIP translation units of libedrgp_hip.so.
+// gfx950 (MI355X / CDNA4) only: 64-wide wavefronts, v_mfma_f64_16x16x4_f64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdarg>
+#include <string>
+#include <vector>
+#include "../../include/edrgp_hip.h"
+
+namespace edrgp {
+
+void set_error(const char* fmt, ...);
+
+#define HIP_TRY(expr)                                                              \
+    do {                                                                           \
+        hipError_t _e = (expr);                                                    \
+        if (_e != hipSuccess) {                                                    \
+            edrgp::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,         \
+                             hipGetErrorString(_e));                               \
+            return EDRGP_ERR_HIP;                                                  \
+        }                                                                          \
+    } while (0)
+
+#define TRY(expr)                                                                  \
+    do {                                                                           \
+        int _s = (expr);                                                           \
+        if (_s != EDRGP_OK) return _s;                                             \
+    } while (0)
+
+// ---------------------------------------------------------------- kernels spec
+struct KSpec {                       // passed by value to device kernels
+    int nparts;
+    int D;
+    int kind[EDRGP_MAX_PARTS];
+    double var[EDRGP_MAX_PARTS];
+    const double* invl;              // device, nparts x D : 1 / lengthscale
+};
+
+// ------------------------------------------------------------ grow-only buffer
+struct DBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t need);        // grow-only (hipMalloc)
+    void release();
+    double* d() const { return static_cast<double*>(p); }
+};
+
+// ------------------------------------------------------------------- profiling
+struct ProfSlot {
+    double total_ms = 0.0;
+    int64_t launches = 0;
+};
+
+struct Ctx;
+
+struct ProfScope {                   // records start/stop events on ctx->stream
+    Ctx* c;
+    int slot;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(Ctx* c, int slot);
+    ~ProfScope();
+};
+
+// ------------------------------------------------------------------------ GEMM
+struct GemmOpts {
+    int tag = 0;                             // kernel symbol tag: 0 generic, 1 Phi syrk, 2 gradient W = K S
+    int batch = 1;
+    long long strideA = 0, strideB = 0, strideC = 0;
+    int limM_base = 0, limM_stride = 0;      // M_eff(z) = min(M, limM_base - z*limM_stride)
+    int limK_base = 0, limK_stride = 0;      // K_eff(z) likewise
+    int tri = 0;                             // 1: only tiles with ti >= tj (M == N)
+    int force_tile = 0;                      // 64 or 128; 0 = heuristic
+};
+
+// C = alpha * op(A) op(B) + beta * C, row-major fp64, MFMA f64 16x16x4.
+int gemm(Ctx* c, bool transA, bool transB, int M, int N, int K, double alpha,
+         const double* A, int lda, const double* B, int ldb, double beta, double* C, int ldc,
+         const GemmOpts& o = GemmOpts());
+
+// Phi (M x M, full symmetric) = K^T K (+ Phi if accumulate), K is rows x M with
+// leading dimension ldk.  Lower-triangular tiles, split over rows into slabs,
+// deterministic slab reduction + mirror.
+int syrk_tn(Ctx* c, const double* K, int64_t rows, int M, int ldk, double* Phi, int ldphi,
+            bool accumulate);
+
+// ------------------------------------------------------- Cholesky / triangular
+// In-place lower Cholesky of the n x n matrix A (row-major, lda); the strict
+// upper triangle is zeroed.  *info_dev (device int) receives 0 or the 1-based
+// index of the first non-positive pivot.
+int potrf_lower(Ctx* c, double* A, int n, int lda, int* info_dev);
+// Linv = L^-1 for lower-triangular L (explicit zeros above the diagonal of the output).
+int trtri_lower(Ctx* c, const double* L, int ldl, double* Linv, int ldi, int n);
+
+// -------------------------------------------------------------- vector helpers
+int gemv_n(Ctx* c, int M, int N, double alpha, const double* A, int lda, const double* x, double* y);
+int gemv_t(Ctx* c, int M, int N, double alpha, const double* A, int lda, const double* x, double* y);
+int add_diag(Ctx* c, double* A, int n, int lda, double v);
+int sum_sq(Ctx* c, const double* x, int64_t n, double* out);               // out[0] = sum x^2
+int dot(Ctx* c, const double* x, const double* y, int64_t n, double* out);
+int trace_of(Ctx* c, const double* A, int n, int lda, double* out);
+int sum_log_diag(Ctx* c, const double* A, int n, int lda, double* out);
+int diag_mean(Ctx* c, const double* A, int n, int lda, double* out);
+int diag_minmax(Ctx* c, const double* A, int n, int lda, double* out2);   // out2 = {min, max} of diag
+int frob_sq(Ctx* c, const double* A, int n, int lda, double* out);       // sum of squares n x n
+int col_reduce(Ctx* c, const double* part, int nparts, int n, double* out); // out[j] = sum_p part[p][j]
+// C = a*A + b*B + g * w w^T  (n x n, all ld = n)
+int combine3(Ctx* c, int n, double a, const double* A, double b, const double* B, double cc,
+             const double* Cm, double g, const double* w, double* out);
+
+// ----------------------------------------------------------------- GP kernels
+// K (rows x M2, ld = ldk) = k(X[r0:r0+rows], X2); if X2 == X and same==1 the
+// diagonal r2 is exactly 0 and `jitter` is added there.  If y != nullptr also
+// accumulates bpart[chunk][m] = sum_rows K[r][m] y[r] (partial sums; nchunk out).
+int kernel_matrix(Ctx* c, const KSpec& ks, const double* X, int64_t rows, const double* X2, int M2,
+                  double* K, int ldk, int same, double jitter,
+                  const double* y, double* bvec /* M2, overwritten */);
+// T = (W + ycoef * y wv^T) .* h_part(r) (0 where r == 0); dvar_out += sum (..) .* K_part / var
+int grad_elementwise(Ctx* c, const KSpec& ks, int part, const double* X, const double* y, int64_t rows,
+                     const double* Z, int M, const double* W, int ldw, double ycoef, const double* wv,
+                     double* T, int ldt, double* dvar_accum /* device scalar, += */);
+// Xt = [X | 1 | X.*X]  (rows x (2D+1))
+int build_xtilde(Ctx* c, const double* X, int64_t rows, int D, double* Xt);
+int rowdot(Ctx* c, const double* A, const double* B, int64_t rows, int cols, int ld, double* out);
+// posterior mean / latent variance / mean Jacobian for one device-resident row chunk
+int predict_chunk(Ctx* c, const KSpec& ks, const double* Xs, int64_t rows, const double* P, const double* Pt,
+                  int Mp, const double* wv, const double* winv, double kdiag, double* Kbuf, double* Gbuf,
+                  double* GT, double* mean, double* var, double* jac);
+int vec_axpy(Ctx* c, int64_t n, double a, const double* x, double* y);   // y += a x
+int calib_mfma_f64(Ctx* c, double* tflops);
+int calib_hbm_copy(Ctx* c, double* gbps);
+int mfma_layout_probe(Ctx* c, const double* A, const double* B, double* C);  // device ptrs
+
+// --------------------------------------------------------------------- context
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cu = 256;
+
+    // data
+    int64_t N = 0;
+    int D = 0;
+    int M = 0;
+    DBuf X, y, Z, Xt, Zt;             // Xt = [X|1|X.^2], Zt likewise for Z
+    bool have_data = false, have_Z = false, have_kernel = false;
+    double yy_local = 0.0;
+
+    // kernel (host copy)
+    int nparts = 0;
+    int kind[EDRGP_MAX_PARTS];
+    double var[EDRGP_MAX_PARTS];
+    std::vector<double> lens;         // nparts x D
+    double noise_var = 1.0;
+    DBuf invl;
+
+    // options
+    int64_t chunk_rows = 131072;
+    int syrk_splits = 0;              // 0 = auto
+    bool profile = false;
+    int stats_mode = 0;               // 0 auto, 1 gram (Phi = K^T K), 2 stable (K Li^T first)
+    double pivot_ratio_max = 1e3;     // auto: stable when (max/min diag Lm)^2 exceeds this
+    int last_mode = 0;
+
+    // posterior (for predict)
+    bool have_post = false;
+    bool post_dense = false;
+    int P = 0;                        // number of posterior basis points
+    DBuf wv, winv;
+
+    // workspace
+    DBuf Knm, W, T;                   // chunk x M
+    DBuf mats[16];                    // M x M (or N x N dense) matrices
+    DBuf slabs, bpart, scal, info, gt_nm, gt_mm, tmpvec[6], panel, trtri_ws, dinv, red;
+    std::vector<double> host_scal;
+
+    // comm
+    void* comm = nullptr;             // ncclComm_t
+    int nranks = 1, rank = 0;
+
+    // profiling
+    ProfSlot prof[EDRGP_PROF_NSLOTS];
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending_events;
+    int drain_events();
+};
+
+int allreduce_sum(Ctx* c, double* buf, size_t count);
+
+}  // namespace edrgp

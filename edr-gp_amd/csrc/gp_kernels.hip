@@ -1,0 +1,375 @@
+// Stationary-kernel tile kernels: RBF / Matern32 / Matern52 covariance assembly
+// (GPy kern.K, stationary.py/rbf.py), the element-wise factors of
+// Stationary.gradients_X / update_gradients_full, and small finishing kernels.
+//
+// pair_kernel<MODE>: a workgroup (256 threads, 16x16, 4x4 outputs per thread)
+// walks 64-row sub-tiles of X against one 64-column tile of X2.  Scaled inputs
+// x/l are staged transposed in LDS ([q][row], 16-byte readable) so the inner
+// loop is 2 ds_read_b128 per operand and 16 (sub, fma) pairs per dimension;
+// global reads of X / X2 are coalesced along the feature dimension.
+//   MODE_K : out = sum_p k_p(r_p)  (+ jitter on the diagonal when X2 is X)
+//            and, when y is given, per-row-chunk partial sums of K^T y
+//   MODE_G : out = wv[m] * h_p(r)            h = (dk/dr)/r, 0 where r == 0
+//   MODE_T : out = Q .* h_p(r),  Q = W + ycoef * y[n] * wv[m];
+//            dvpart[block] = sum Q .* k_p / var_p
+#include "common.h"
+
+namespace edrgp {
+
+constexpr int MODE_K = 0, MODE_G = 1, MODE_T = 2;
+constexpr int DT = 32;          // feature chunk staged in LDS
+constexpr int TS = 64;          // tile side
+constexpr int TP = TS + 2;      // padded row (16-byte aligned rows)
+
+struct PairArgs {
+    KSpec ks;
+    int part;
+    const double* X;
+    int64_t rows;
+    const double* X2;
+    int M2;
+    double* out;
+    int ldo;
+    int same;
+    double jitter;
+    const double* y;
+    double* bpart;
+    const double* W;
+    int ldw;
+    double ycoef;
+    const double* wv;
+    double* dvpart;
+    int rows_per_block;
+};
+
+#define SQRT3 1.7320508075688772
+#define SQRT5 2.23606797749979
+
+__device__ __forceinline__ void kfun(int kind, double var, double r2, double& K, double& h) {
+    if (kind == EDRGP_KERN_RBF) {
+        K = var * exp(-0.5 * r2);
+        h = -K;
+    } else if (kind == EDRGP_KERN_MATERN32) {
+        const double r = sqrt(r2);
+        const double e = exp(-SQRT3 * r);
+        K = var * (1.0 + SQRT3 * r) * e;
+        h = -3.0 * var * e;
+    } else {
+        const double r = sqrt(r2);
+        const double e = exp(-SQRT5 * r);
+        K = var * (1.0 + SQRT5 * r + (5.0 / 3.0) * r2) * e;
+        h = -(5.0 / 3.0) * var * (1.0 + SQRT5 * r) * e;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void pair_kernel(PairArgs a) {
+    __shared__ __attribute__((aligned(16))) double Xs[DT][TP];
+    __shared__ __attribute__((aligned(16))) double Zs[DT][TP];
+    __shared__ double red[16][TS];
+
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int D = a.ks.D;
+    const int col0 = blockIdx.x * TS;
+    const int64_t rb0 = (int64_t)blockIdx.y * a.rows_per_block;
+    const int p_begin = (MODE == MODE_K) ? 0 : a.part;
+    const int p_end = (MODE == MODE_K) ? a.ks.nparts : a.part + 1;
+
+    double bacc[4] = {0.0, 0.0, 0.0, 0.0};
+    double dvacc = 0.0;
+
+    for (int sub = 0; sub * TS < a.rows_per_block; ++sub) {
+        const int64_t row0 = rb0 + (int64_t)sub * TS;
+        if (row0 >= a.rows) break;
+
+        double outv[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) outv[i][j] = 0.0;
+
+        double Kp[4][4];
+        for (int p = p_begin; p < p_end; ++p) {
+            double r2[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r2[i][j] = 0.0;
+            const double* invl = a.ks.invl + (size_t)p * D;
+            for (int d0 = 0; d0 < D; d0 += DT) {
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < (TS * DT) / 256; ++e) {
+                    const int idx = tid + 256 * e;
+                    const int rr = idx / DT, q = idx % DT;
+                    const int dq = d0 + q;
+                    double xv = 0.0, zv = 0.0;
+                    if (dq < D) {
+                        const double il = invl[dq];
+                        if (row0 + rr < a.rows) xv = a.X[(size_t)(row0 + rr) * D + dq] * il;
+                        if (col0 + rr < a.M2) zv = a.X2[(size_t)(col0 + rr) * D + dq] * il;
+                    }
+                    Xs[q][rr] = xv;
+                    Zs[q][rr] = zv;
+                }
+                __syncthreads();
+                const int qn = min(DT, D - d0);
+                for (int q = 0; q < qn; ++q) {
+                    const double2 x01 = *reinterpret_cast<const double2*>(&Xs[q][ty * 4]);
+                    const double2 x23 = *reinterpret_cast<const double2*>(&Xs[q][ty * 4 + 2]);
+                    const double2 z01 = *reinterpret_cast<const double2*>(&Zs[q][tx * 4]);
+                    const double2 z23 = *reinterpret_cast<const double2*>(&Zs[q][tx * 4 + 2]);
+                    const double xv[4] = {x01.x, x01.y, x23.x, x23.y};
+                    const double zv[4] = {z01.x, z01.y, z23.x, z23.y};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const double d = xv[i] - zv[j];
+                            r2[i][j] = fma(d, d, r2[i][j]);
+                        }
+                }
+            }
+            const int kind = a.ks.kind[p];
+            const double var = a.ks.var[p];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    double K, h;
+                    kfun(kind, var, r2[i][j], K, h);
+                    if (MODE == MODE_K) {
+                        outv[i][j] += K;
+                    } else {
+                        Kp[i][j] = K;
+                        outv[i][j] = (r2[i][j] == 0.0) ? 0.0 : h;   // _inv_dist = 0 at r == 0
+                    }
+                }
+        }
+
+        // ---- epilogue for this 64x64 sub-tile
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t row = row0 + ty * 4 + i;
+            if (row >= a.rows) continue;
+            const double yr = (a.y != nullptr) ? a.y[row] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = col0 + tx * 4 + j;
+                if (col >= a.M2) continue;
+                double v = outv[i][j];
+                if (MODE == MODE_K) {
+                    if (a.same && row == (int64_t)col) v += a.jitter;
+                    bacc[j] = fma(v, yr, bacc[j]);
+                } else if (MODE == MODE_G) {
+                    v *= a.wv[col];
+                } else {
+                    double Q = a.W[(size_t)row * a.ldw + col];
+                    if (a.wv != nullptr) Q = fma(a.ycoef * yr, a.wv[col], Q);
+                    dvacc = fma(Q, Kp[i][j], dvacc);
+                    v *= Q;
+                }
+                a.out[(size_t)row * a.ldo + col] = v;
+            }
+        }
+    }
+
+    if (MODE == MODE_K && a.bpart != nullptr) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[ty][tx * 4 + j] = bacc[j];
+        __syncthreads();
+        if (tid < TS) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s += red[k][tid];
+            if (col0 + tid < a.M2) a.bpart[(size_t)blockIdx.y * a.M2 + col0 + tid] = s;
+        }
+    }
+    if (MODE == MODE_T && a.dvpart != nullptr) {
+        __syncthreads();
+        red[ty][tx] = dvacc;
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int k = 0; k < 16; ++k)
+                for (int l = 0; l < 16; ++l) s += red[k][l];
+            a.dvpart[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s / a.ks.var[a.part];
+        }
+    }
+}
+
+static int pick_rows_per_block(int64_t rows, int col_tiles) {
+    // enough workgroups to fill 256 CUs several times, at most 1024 rows each
+    int rpb = 1024;
+    while (rpb > 64 && (int64_t)col_tiles * ((rows + rpb - 1) / rpb) < 2048) rpb >>= 1;
+    return rpb;
+}
+
+int kernel_matrix(Ctx* c, const KSpec& ks, const double* X, int64_t rows, const double* X2, int M2, double* K,
+                  int ldk, int same, double jitter, const double* y, double* bvec) {
+    if (rows <= 0 || M2 <= 0) return EDRGP_OK;
+    PairArgs a{};
+    a.ks = ks; a.part = 0; a.X = X; a.rows = rows; a.X2 = X2; a.M2 = M2; a.out = K; a.ldo = ldk;
+    a.same = same; a.jitter = jitter; a.y = y; a.W = nullptr; a.wv = nullptr; a.dvpart = nullptr;
+    const int ct = (M2 + TS - 1) / TS;
+    a.rows_per_block = pick_rows_per_block(rows, ct);
+    const int nchunk = (int)((rows + a.rows_per_block - 1) / a.rows_per_block);
+    a.bpart = nullptr;
+    if (y != nullptr) {
+        TRY(c->bpart.reserve((size_t)nchunk * M2 * sizeof(double)));
+        a.bpart = c->bpart.d();
+    }
+    hipLaunchKernelGGL(pair_kernel<MODE_K>, dim3(ct, nchunk), dim3(256), 0, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    if (y != nullptr) TRY(col_reduce(c, c->bpart.d(), nchunk, M2, bvec));
+    return EDRGP_OK;
+}
+
+// G = wv[m] * h_part(r)   (rows x Mp)
+static int hmatrix(Ctx* c, const KSpec& ks, int part, const double* Xs, int64_t rows, const double* P, int Mp,
+                   const double* wv, double* G, int ldg) {
+    PairArgs a{};
+    a.ks = ks; a.part = part; a.X = Xs; a.rows = rows; a.X2 = P; a.M2 = Mp; a.out = G; a.ldo = ldg;
+    a.wv = wv;
+    const int ct = (Mp + TS - 1) / TS;
+    a.rows_per_block = pick_rows_per_block(rows, ct);
+    const int nchunk = (int)((rows + a.rows_per_block - 1) / a.rows_per_block);
+    hipLaunchKernelGGL(pair_kernel<MODE_G>, dim3(ct, nchunk), dim3(256), 0, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    return EDRGP_OK;
+}
+
+__global__ __launch_bounds__(256) void sum_add_kernel(const double* __restrict__ part, int n,
+                                                      double* __restrict__ accum) {
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) accum[0] += sh[0];
+}
+
+int grad_elementwise(Ctx* c, const KSpec& ks, int part, const double* X, const double* y, int64_t rows,
+                     const double* Z, int M, const double* W, int ldw, double ycoef, const double* wv, double* T,
+                     int ldt, double* dvar_accum) {
+    PairArgs a{};
+    a.ks = ks; a.part = part; a.X = X; a.rows = rows; a.X2 = Z; a.M2 = M; a.out = T; a.ldo = ldt;
+    a.y = y; a.W = W; a.ldw = ldw; a.ycoef = ycoef; a.wv = wv;
+    const int ct = (M + TS - 1) / TS;
+    a.rows_per_block = pick_rows_per_block(rows, ct);
+    const int nchunk = (int)((rows + a.rows_per_block - 1) / a.rows_per_block);
+    TRY(c->red.reserve((size_t)nchunk * ct * sizeof(double)));
+    a.dvpart = c->red.d();
+    hipLaunchKernelGGL(pair_kernel<MODE_T>, dim3(ct, nchunk), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(sum_add_kernel, dim3(1), dim3(256), 0, c->stream, c->red.d(), nchunk * ct, dvar_accum);
+    HIP_TRY(hipGetLastError());
+    return EDRGP_OK;
+}
+
+// Xt[n] = [x_n | 1 | x_n .* x_n]
+__global__ void xtilde_kernel(const double* __restrict__ X, int64_t rows, int D, double* __restrict__ Xt) {
+    const int W = 2 * D + 1;
+    const int64_t total = rows * W;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t n = i / W;
+        const int q = (int)(i - n * W);
+        double v;
+        if (q < D) v = X[n * D + q];
+        else if (q == D) v = 1.0;
+        else { const double x = X[n * D + (q - D - 1)]; v = x * x; }
+        Xt[i] = v;
+    }
+}
+
+int build_xtilde(Ctx* c, const double* X, int64_t rows, int D, double* Xt) {
+    const int64_t total = rows * (2 * D + 1);
+    const int nb = (int)std::min<int64_t>(4096, (total + 255) / 256);
+    hipLaunchKernelGGL(xtilde_kernel, dim3(std::max(nb, 1)), dim3(256), 0, c->stream, X, rows, D, Xt);
+    HIP_TRY(hipGetLastError());
+    return EDRGP_OK;
+}
+
+// out[n] = sum_j A[n][j] * B[n][j]; one wave per row
+__global__ __launch_bounds__(256) void rowdot_kernel(const double* __restrict__ A, const double* __restrict__ B,
+                                                     int64_t rows, int cols, int ld, double* __restrict__ out) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const double* a = A + (size_t)row * ld;
+    const double* b = B + (size_t)row * ld;
+    double s = 0.0;
+    for (int j = lane; j < cols; j += 64) s += a[j] * b[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) out[row] = s;
+}
+
+int rowdot(Ctx* c, const double* A, const double* B, int64_t rows, int cols, int ld, double* out) {
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream, A, B, rows,
+                       cols, ld, out);
+    HIP_TRY(hipGetLastError());
+    return EDRGP_OK;
+}
+
+// jac[n][q] (+)= invl[q]^2 * (x[n][q] * GT[n][D] - GT[n][q]);  GT is rows x (2D+1)
+__global__ void jac_finish_kernel(const double* __restrict__ Xs, const double* __restrict__ GT, int64_t rows,
+                                  int D, const double* __restrict__ invl, int accumulate,
+                                  double* __restrict__ jac) {
+    const int W = 2 * D + 1;
+    const int64_t total = rows * D;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t n = i / D;
+        const int q = (int)(i - n * D);
+        const double il = invl[q];
+        const double v = il * il * (Xs[i] * GT[n * W + D] - GT[n * W + q]);
+        jac[i] = accumulate ? jac[i] + v : v;
+    }
+}
+
+// var[n] = max(kdiag - quad[n], 1e-15)
+__global__ void var_finish_kernel(double* var, int64_t rows, double kdiag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows) var[i] = fmax(kdiag - var[i], 1e-15);
+}
+
+// Posterior mean (K wv), latent variance and mean Jacobian on one row chunk of
+// device-resident test inputs.  Buffers: Kbuf / Gbuf are rows x Mp scratch.
+int predict_chunk(Ctx* c, const KSpec& ks, const double* Xs, int64_t rows, const double* P, const double* Pt,
+                  int Mp, const double* wv, const double* winv, double kdiag, double* Kbuf, double* Gbuf,
+                  double* GT, double* mean, double* var, double* jac) {
+    const int D = ks.D;
+    if (mean != nullptr || var != nullptr) {
+        TRY(kernel_matrix(c, ks, Xs, rows, P, Mp, Kbuf, Mp, 0, 0.0, nullptr, nullptr));
+        if (mean != nullptr) TRY(gemv_n(c, (int)rows, Mp, 1.0, Kbuf, Mp, wv, mean));
+        if (var != nullptr) {
+            // quad[n] = sum_m (K Winv)[n][m] K[n][m]
+            TRY(gemm(c, false, false, (int)rows, Mp, Mp, 1.0, Kbuf, Mp, winv, Mp, 0.0, Gbuf, Mp));
+            TRY(rowdot(c, Gbuf, Kbuf, rows, Mp, Mp, var));
+            hipLaunchKernelGGL(var_finish_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, c->stream,
+                               var, rows, kdiag);
+        }
+    }
+    if (jac != nullptr) {
+        const int Wd = 2 * D + 1;
+        for (int p = 0; p < ks.nparts; ++p) {
+            TRY(hmatrix(c, ks, p, Xs, rows, P, Mp, wv, Gbuf, Mp));
+            TRY(gemm(c, false, false, (int)rows, Wd, Mp, 1.0, Gbuf, Mp, Pt, Wd, 0.0, GT, Wd));
+            const int64_t total = rows * D;
+            const int nb = (int)std::min<int64_t>(4096, (total + 255) / 256);
+            hipLaunchKernelGGL(jac_finish_kernel, dim3(std::max(nb, 1)), dim3(256), 0, c->stream, Xs, GT, rows, D,
+                               ks.invl + (size_t)p * D, p > 0 ? 1 : 0, jac);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return EDRGP_OK;
+}
+
+}  // namespace edrgp

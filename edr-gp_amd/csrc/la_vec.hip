@@ -1,0 +1,233 @@
+// Small fp64 helpers around the MFMA kernels: gemv, reductions with a fixed
+// (deterministic) summation order, element-wise combinations of M x M matrices.
+#include "common.h"
+
+namespace edrgp {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// block-wide sum (256 threads); result valid in thread 0
+__device__ __forceinline__ double block_sum256(double v) {
+    __shared__ double part[4];
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) part[w] = v;
+    __syncthreads();
+    return (threadIdx.x == 0) ? (part[0] + part[1]) + (part[2] + part[3]) : 0.0;
+}
+
+// y[i] = alpha * sum_j A[i][j] x[j]; one wave per row
+__global__ __launch_bounds__(256) void gemv_n_kernel(int M, int N, double alpha, const double* __restrict__ A,
+                                                     int lda, const double* __restrict__ x,
+                                                     double* __restrict__ y) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const double* a = A + (size_t)row * lda;
+    double s = 0.0;
+    for (int j = lane; j < N; j += 64) s += a[j] * x[j];
+    s = wave_sum(s);
+    if (lane == 0) y[row] = alpha * s;
+}
+
+// part[chunk][j] = sum_{i in chunk} A[i][j] x[i]; chunk = 128 rows, 64 columns per block
+__global__ __launch_bounds__(256) void gemv_t_part_kernel(int M, int N, const double* __restrict__ A, int lda,
+                                                          const double* __restrict__ x,
+                                                          double* __restrict__ part) {
+    __shared__ double red[4][64];
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int sub = threadIdx.x >> 6;
+    const int i0 = blockIdx.y * 128;
+    const int i1 = min(M, i0 + 128);
+    double s = 0.0;
+    if (j < N)
+        for (int i = i0 + sub; i < i1; i += 4) s += A[(size_t)i * lda + j] * x[i];
+    red[sub][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sub == 0 && j < N)
+        part[(size_t)blockIdx.y * N + j] = (red[0][threadIdx.x] + red[1][threadIdx.x]) +
+                                           (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// out[j] = alpha * sum_p part[p][j]
+__global__ void col_reduce_kernel(const double* __restrict__ part, int nparts, int n, double alpha,
+                                  double* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    double s = 0.0;
+    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * n + j];
+    out[j] = alpha * s;
+}
+
+int gemv_n(Ctx* c, int M, int N, double alpha, const double* A, int lda, const double* x, double* y) {
+    hipLaunchKernelGGL(gemv_n_kernel, dim3((M + 3) / 4), dim3(256), 0, c->stream, M, N, alpha, A, lda, x, y);
+    HIP_TRY(hipGetLastError());
+    return EDRGP_OK;
+}
+
+// y[j] = alpha * sum_i A[i][j] x[i]   (A is M x N)
+int gemv_t(Ctx* c, int M, int N, double alpha, const double* A, int lda, const double* x, double* y) {
+    const int nchunk = (M + 127) / 128;
+    TRY(c->red.reserve((size_t)nchunk * N * sizeof(double)));
+    hipLaunchKernelGGL(gemv_t_part_kernel, dim3((N + 63) / 64, nchunk), dim3(256), 0, c->stream, M, N, A, lda,
+                       x, c->red.d());
+    hipLaunchKernelGGL(col_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->red.d(), nchunk, N,
+                       alpha, y);
+    HIP_TRY(hipGetLastError());
+    return EDRGP_OK;
+}
+
+int col_reduce(Ctx* c, const double* part, int nparts, int n, double* out) {
+    hipLaunchKernelGGL(col_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, part, nparts, n, 1.0,
+                       out);
+    HIP_TRY(hipGetLastError());
+    return EDRGP_OK;
+}
+
+__global__ void add_diag_kernel(double* A, int n, int lda, double v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) A[(size_t)i * lda + i] += v;
+}
+
+int add_diag(Ctx* c, double* A, int n, int lda, double v) {
+    hipLaunchKernelGGL(add_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, A, n, lda, v);
+    HIP_TRY(hipGetLastError());
+    return EDRGP_OK;
+}
+
+// Generic single-block reduction with a fixed order: mode selects the summand.
+//  0: x[i]^2   1: x[i]*y[i]   2: A[i][i]   3: log(A[i][i])   4: A[i][i]/n
+__global__ __launch_bounds__(256) void reduce1_kernel(int mode, const double* __restrict__ x,
+                                                      const double* __restrict__ y, int64_t n, int lda,
+                                                      double* __restrict__ out) {
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        double v;
+        if (mode == 0) v = x[i] * x[i];
+        else if (mode == 1) v = x[i] * y[i];
+        else if (mode == 2) v = x[(size_t)i * lda + i];
+        else if (mode == 3) v = log(x[(size_t)i * lda + i]);
+        else v = x[(size_t)i * lda + i] / (double)n;
+        s += v;
+    }
+    s = block_sum256(s);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+// two-stage sum of squares for long vectors / matrices: per-block partials then one block
+__global__ __launch_bounds__(256) void sumsq_part_kernel(const double* __restrict__ x, int64_t n,
+                                                         const double* __restrict__ y,
+                                                         double* __restrict__ part) {
+    double s = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+        s += x[i] * (y ? y[i] : x[i]);
+    s = block_sum256(s);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void sum_part_kernel(const double* __restrict__ part, int n,
+                                                       double* __restrict__ out) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+    s = block_sum256(s);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+static int long_dot(Ctx* c, const double* x, const double* y, int64_t n, double* out) {
+    if (n <= 4096) {
+        hipLaunchKernelGGL(reduce1_kernel, dim3(1), dim3(256), 0, c->stream, y ? 1 : 0, x, y, n, 0, out);
+    } else {
+        const int nb = (int)std::min<int64_t>(1024, (n + 1023) / 1024);
+        TRY(c->red.reserve((size_t)nb * sizeof(double)));
+        hipLaunchKernelGGL(sumsq_part_kernel, dim3(nb), dim3(256), 0, c->stream, x, n, y, c->red.d());
+        hipLaunchKernelGGL(sum_part_kernel, dim3(1), dim3(256), 0, c->stream, c->red.d(), nb, out);
+    }
+    HIP_TRY(hipGetLastError());
+    return EDRGP_OK;
+}
+
+int sum_sq(Ctx* c, const double* x, int64_t n, double* out) { return long_dot(c, x, nullptr, n, out); }
+int dot(Ctx* c, const double* x, const double* y, int64_t n, double* out) { return long_dot(c, x, y, n, out); }
+int frob_sq(Ctx* c, const double* A, int n, int lda, double* out) {
+    if (lda != n) { set_error("frob_sq: lda must equal n"); return EDRGP_ERR_INVALID; }
+    return long_dot(c, A, nullptr, (int64_t)n * n, out);
+}
+
+int trace_of(Ctx* c, const double* A, int n, int lda, double* out) {
+    hipLaunchKernelGGL(reduce1_kernel, dim3(1), dim3(256), 0, c->stream, 2, A, (const double*)nullptr,
+                       (int64_t)n, lda, out);
+    HIP_TRY(hipGetLastError());
+    return EDRGP_OK;
+}
+int sum_log_diag(Ctx* c, const double* A, int n, int lda, double* out) {
+    hipLaunchKernelGGL(reduce1_kernel, dim3(1), dim3(256), 0, c->stream, 3, A, (const double*)nullptr,
+                       (int64_t)n, lda, out);
+    HIP_TRY(hipGetLastError());
+    return EDRGP_OK;
+}
+int diag_mean(Ctx* c, const double* A, int n, int lda, double* out) {
+    hipLaunchKernelGGL(reduce1_kernel, dim3(1), dim3(256), 0, c->stream, 4, A, (const double*)nullptr,
+                       (int64_t)n, lda, out);
+    HIP_TRY(hipGetLastError());
+    return EDRGP_OK;
+}
+
+__global__ __launch_bounds__(256) void diag_minmax_kernel(const double* __restrict__ A, int n, int lda,
+                                                         double* __restrict__ out2) {
+    __shared__ double smin[256], smax[256];
+    double mn = INFINITY, mx = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const double v = A[(size_t)i * lda + i];
+        mn = fmin(mn, v);
+        mx = fmax(mx, v);
+    }
+    smin[threadIdx.x] = mn;
+    smax[threadIdx.x] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            smin[threadIdx.x] = fmin(smin[threadIdx.x], smin[threadIdx.x + o]);
+            smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + o]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out2[0] = smin[0]; out2[1] = smax[0]; }
+}
+
+int diag_minmax(Ctx* c, const double* A, int n, int lda, double* out2) {
+    hipLaunchKernelGGL(diag_minmax_kernel, dim3(1), dim3(256), 0, c->stream, A, n, lda, out2);
+    HIP_TRY(hipGetLastError());
+    return EDRGP_OK;
+}
+
+// out = a*A + b*B + cc*Cm + g * w w^T   (n x n, ld n); null matrices are skipped
+__global__ void combine3_kernel(int n, double a, const double* __restrict__ A, double b,
+                                const double* __restrict__ B, double cc, const double* __restrict__ Cm,
+                                double g, const double* __restrict__ w, double* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i >= n || j >= n) return;
+    const size_t idx = (size_t)i * n + j;
+    double v = 0.0;
+    if (A) v += a * A[idx];
+    if (B) v += b * B[idx];
+    if (Cm) v += cc * Cm[idx];
+    if (w) v += g * w[i] * w[j];
+    out[idx] = v;
+}
+
+int combine3(Ctx* c, int n, double a, const double* A, double b, const double* B, double cc, const double* Cm,
+             double g, const double* w, double* out) {
+    dim3 blk(64, 4), grd((n + 63) / 64, (n + 3) / 4);
+    hipLaunchKernelGGL(combine3_kernel, grd, blk, 0, c->stream, n, a, A, b, B, cc, Cm, g, w, out);
+    HIP_TRY(hipGetLastError());
+    return EDRGP_OK;
+}
+
+}  // namespace edrgp

@@ -1,0 +1,159 @@
+/*
+ * edrgp_hip.h -- C ABI of the MI355X (gfx950) sparse-GP inference core.
+ *
+ * The reference (neuro-ml/edr-gp) is pure Python and has no FFI: its GP
+ * arithmetic is delegated to GPy through
+ *     edrgp/gp_model/regression.py:76-77   (GPRegression)
+ *     edrgp/gp_model/regression.py:153-157 (SparseGPRegression)
+ *     edrgp/gp_model/base.py:69            (model.optimize -> one inference per iteration)
+ *     edrgp/gp_model/base.py:187,206       (model.predict)
+ *     edrgp/gp_model/base.py:222           (model.predictive_gradients)
+ * Each entry point below replaces the GPy unit those call sites reach; the
+ * Python side (edr-gp_amd/gp_model) binds them with ctypes and keeps the
+ * reference's estimator API.  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; every function returns an int
+ *     status: 0 = ok, negative = error (text via edrgp_last_error()).
+ *   - All matrices are row-major fp64.  Host pointers are borrowed for the
+ *     duration of the call only.  Device state lives in the opaque context.
+ *   - One context <-> one HIP device <-> one HIP stream.  A context is not
+ *     thread-safe; different contexts may be used from different threads.
+ *   - Nothing here falls back to the CPU: without a gfx950 device
+ *     edrgp_ctx_create fails with EDRGP_ERR_HIP.
+ */
+#ifndef EDRGP_HIP_H
+#define EDRGP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct edrgp_ctx edrgp_ctx;
+
+/* status codes */
+#define EDRGP_OK            0
+#define EDRGP_ERR_INVALID  -1   /* bad argument / shape */
+#define EDRGP_ERR_NOT_PD   -2   /* Cholesky failed even after the jitchol retries */
+#define EDRGP_ERR_HIP      -3   /* HIP runtime error (no device, OOM, launch failure) */
+#define EDRGP_ERR_STATE    -4   /* call order: data / inducing / kernel / posterior missing */
+#define EDRGP_ERR_COMM     -5   /* RCCL error */
+
+/* stationary kernel kinds: GPy.kern.{RBF,Matern32,Matern52}
+ * (names resolved by _make_kernel, edrgp/gp_model/base.py:134-146) */
+#define EDRGP_KERN_RBF       0
+#define EDRGP_KERN_MATERN32  1
+#define EDRGP_KERN_MATERN52  2
+#define EDRGP_MAX_PARTS      4   /* additive parts of a sum kernel (base.py:146) */
+#define EDRGP_MAX_DIM        256 /* input dimension limit */
+
+/* edrgp_get() selectors (debug / parity accessors) */
+#define EDRGP_GET_PHI        1   /* K_mn K_nm (Gram form) or Lm^-1 K_mn K_nm Lm^-T (stable form) */
+#define EDRGP_GET_BVEC       2   /* K_mn y (Gram form) or Lm^-1 K_mn y (stable form) */
+#define EDRGP_GET_LM         3   /* chol(Kmm + 1e-8 I)   (M x M, lower) */
+#define EDRGP_GET_LB         4   /* chol(I + A)          (M x M, lower) */
+#define EDRGP_GET_A          5   /* beta Lm^-1 Phi Lm^-T (M x M) */
+#define EDRGP_GET_WV         6   /* woodbury vector      (P)     */
+#define EDRGP_GET_WINV       7   /* woodbury inverse     (P x P) */
+#define EDRGP_GET_KMM        8   /* Kmm + jitter         (M x M) */
+#define EDRGP_GET_KNM        9   /* first row chunk of K_nm (rows x M) */
+#define EDRGP_GET_LMI       10   /* Lm^-1                (M x M) */
+#define EDRGP_GET_LBI       11   /* LB^-1                (M x M) */
+#define EDRGP_GET_DLDKMM    12   /* dL/dKmm              (M x M) */
+#define EDRGP_GET_SCALARS   13   /* device scalar slots (16 doubles) */
+#define EDRGP_GET_MODE      14   /* 1: Gram form was used, 2: stable form (buf[0]) */
+
+/* profile slots: device time of kernel families measured with HIP events on
+ * the context's stream (bench.py roofline) */
+#define EDRGP_PROF_SYRK      0   /* Phi = K_mn K_nm fp64 MFMA kernel */
+#define EDRGP_PROF_KBUILD    1   /* K_nm tile build */
+#define EDRGP_PROF_GRADGEMM  2   /* W = K_nm S (gradient contraction) */
+#define EDRGP_PROF_SMALL     3   /* O(M^3) part: Cholesky, trtri, M x M GEMMs */
+#define EDRGP_PROF_NSLOTS    8
+
+const char* edrgp_last_error(void);
+int  edrgp_version(void);
+int  edrgp_device_count(int* count);
+
+int  edrgp_ctx_create(int device, edrgp_ctx** ctx);
+int  edrgp_ctx_destroy(edrgp_ctx* ctx);
+int  edrgp_sync(edrgp_ctx* ctx);
+/* tunables: "chunk_rows", "syrk_splits", "profile" (0/1), "stats_mode" (0 auto,
+ * 1 Gram form Phi = K_mn K_nm, 2 stable form via K_nm Lm^-T), "pivot_ratio_max" */
+int  edrgp_set_option(edrgp_ctx* ctx, const char* key, double value);
+
+/* Training data (already validated / normalised by the host: check_X_y at
+ * gp_model/base.py:87, Standardize at regression.py:48,124).  Copied to HBM
+ * once and kept resident. */
+int  edrgp_set_data(edrgp_ctx* ctx, const double* X, const double* y, int64_t N, int D);
+/* Inducing inputs Z (M x D): GPy SparseGPRegression's Z parameter
+ * (regression.py:153-157).  Re-sent whenever the optimiser moves Z. */
+int  edrgp_set_inducing(edrgp_ctx* ctx, const double* Z, int M);
+/* Kernel hyper-parameters: GPy kern.{variance,lengthscale} + Gaussian_noise.variance.
+ * lengthscales is nparts x D (an isotropic part repeats its value D times). */
+int  edrgp_set_kernel(edrgp_ctx* ctx, int nparts, const int* kinds,
+                      const double* variances, const double* lengthscales,
+                      double noise_var);
+
+/* GPy VarDTC.inference (sparse fit, one call per optimiser iteration):
+ * Titsias bound only. */
+int  edrgp_sparse_lml(edrgp_ctx* ctx, double* lml);
+/* ... bound + gradients: SparseGP._update_gradients.  dvar[nparts],
+ * dlen[nparts*D] (per input dimension; the host sums them for an isotropic
+ * part), dnoise[1], dZ[M*D]. */
+int  edrgp_sparse_lml_grad(edrgp_ctx* ctx, double* lml, double* dvar, double* dlen,
+                           double* dnoise, double* dZ);
+/* Builds woodbury_vector / woodbury_inv for predict (GPy Posterior). */
+int  edrgp_sparse_posterior(edrgp_ctx* ctx, double* lml);
+
+/* GPy ExactGaussianInference.inference (dense fit, config 1): LML and, when
+ * the pointers are non-NULL, its gradients. */
+int  edrgp_dense_lml_grad(edrgp_ctx* ctx, double* lml, double* dvar, double* dlen,
+                          double* dnoise);
+int  edrgp_dense_posterior(edrgp_ctx* ctx, double* lml);
+
+/* GPy Posterior._raw_predict (latent mean / variance, normalised space, no
+ * likelihood noise; var clipped at 1e-15).  var may be NULL. */
+int  edrgp_predict(edrgp_ctx* ctx, const double* Xs, int64_t Ns, double* mean, double* var);
+/* Mean part of GPy GP.predictive_gradients: d mean / d x*, (Ns x D). */
+int  edrgp_predict_grad(edrgp_ctx* ctx, const double* Xs, int64_t Ns, double* grad);
+/* Same as edrgp_predict + edrgp_predict_grad on the resident training X
+ * (what EDR calls: edrgp/base.py:274 with X = training set); outputs host. */
+int  edrgp_predict_train(edrgp_ctx* ctx, double* mean, double* grad);
+
+/* debug / parity accessor */
+int  edrgp_get(edrgp_ctx* ctx, int which, double* buf, int64_t cap_elems);
+
+/* profiling (HIP events on the context's stream) */
+int  edrgp_profile_reset(edrgp_ctx* ctx);
+int  edrgp_profile_get(edrgp_ctx* ctx, int slot, double* total_ms, int64_t* launches);
+
+/* Row-sharded multi-GPU (one process per GPU): all ranks hold the same Z and
+ * hyper-parameters and a row block of (X, y); Phi, K_mn y and the scalars are
+ * sum-all-reduced over RCCL once per evaluation (GPy's own unused precedent:
+ * VarDTC_minibatch + mpi4py Allreduce). */
+int  edrgp_comm_unique_id(void* id128);                 /* 128-byte ncclUniqueId */
+int  edrgp_comm_init(edrgp_ctx* ctx, int nranks, int rank, const void* id128);
+int  edrgp_comm_destroy(edrgp_ctx* ctx);
+
+/* Low-level device linear algebra on host buffers -- test hooks for the
+ * building blocks (row-major fp64). */
+int  edrgp_dbg_gemm(edrgp_ctx* ctx, int transA, int transB, int M, int N, int K,
+                    double alpha, const double* A, int lda, const double* B, int ldb,
+                    double beta, double* C, int ldc);
+int  edrgp_dbg_potrf(edrgp_ctx* ctx, double* A, int n, int* info);
+int  edrgp_dbg_trtri(edrgp_ctx* ctx, const double* L, double* Linv, int n);
+int  edrgp_dbg_syrk(edrgp_ctx* ctx, const double* K, int64_t N, int M, double* Phi);
+int  edrgp_dbg_kernel_matrix(edrgp_ctx* ctx, const double* X, int64_t N,
+                             const double* X2, int64_t N2, int D, double* K);
+int  edrgp_dbg_mfma_layout(edrgp_ctx* ctx, const double* A16x4, const double* B4x16, double* C16x16);
+/* fp64 MFMA issue-rate microbenchmark: achieved TFLOP/s of back-to-back
+ * v_mfma_f64_16x16x4_f64 on every SIMD, and HBM copy bandwidth in GB/s. */
+int  edrgp_calib(edrgp_ctx* ctx, double* mfma_f64_tflops, double* hbm_copy_gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EDRGP_HIP_H */

@@ -1,0 +1,208 @@
+"""GPU parity of the inference pipelines (C ABI) against the CPU oracle.
+
+Sparse: Titsias bound, its gradients, posterior factors, predictions
+(GPy VarDTC.inference / SparseGP._update_gradients / Posterior._raw_predict).
+Dense: exact LML, gradients, predictions (ExactGaussianInference).
+
+Tolerances (fp64): bound <= 1e-10 relative, posterior mean <= 1e-8 relative
+(SURVEY.md section 8d), gradients <= 1e-7 relative to the gradient norm.
+"""
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as go
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def set_kernel(hip, kern, noise):
+    D = kern.input_dim
+    kinds = [p.kind for p in kern.parts]
+    var = [p.variance for p in kern.parts]
+    ls = np.array([np.broadcast_to(p.lengthscale, (D,)) for p in kern.parts])
+    hip.set_kernel(kinds, var, ls, noise)
+
+
+def oracle_sparse(kern, X, y, Z, noise):
+    inf = go.vardtc_inference(kern, X, Z, noise, y[:, None])
+    kg, dn, dZ = go.sparse_gradients(kern, X, Z, inf)
+    return inf, kg, dn, dZ
+
+
+def fold_dlen(kern, dlen):
+    """device returns per-dimension lengthscale gradients; sum them for isotropic parts"""
+    out = []
+    for p, part in enumerate(kern.parts):
+        out.append(dlen[p] if part.ARD else np.array([dlen[p].sum()]))
+    return out
+
+
+CASES = [
+    # (N, M, D, kinds, options, noise)
+    (50, 12, 1, ["RBF"], [dict(variance=1.0, lengthscale=1.0)], 1.0),
+    (256, 32, 4, ["RBF"], [dict(variance=0.8, lengthscale=1.7)], 0.05),
+    (256, 32, 4, ["Matern32"], [dict(variance=1.3, lengthscale=2.0)], 0.1),
+    (512, 64, 8, ["Matern52"], [dict(variance=1.1, lengthscale=2.5)], 0.02),
+    (700, 100, 6, ["RBF"], [dict(variance=0.9, lengthscale=[1.5, 2.0, 2.5, 3.0, 3.5, 4.0], ARD=True)], 0.05),
+    (600, 70, 5, ["RBF", "Matern52"], [dict(variance=0.6, lengthscale=2.0), dict(variance=0.3, lengthscale=1.2)], 0.05),
+    (3000, 200, 16, ["RBF"], [dict(variance=1.0, lengthscale=4.0)], 0.01),
+]
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("N,M,D,kinds,opts,noise", CASES)
+def test_sparse_bound_gradients_posterior(hip, N, M, D, kinds, opts, noise, mode):
+    """mode 0 = automatic choice between the Gram form and the stable form
+    (pivot-ratio proxy of cond(Kmm)); mode 2 = stable form forced."""
+    X, y, Z = go.synthetic_problem(N, D, M, seed=N + M)
+    kern = go.make_kernel(kinds, D, opts)
+    inf, kg, dn, dZ = oracle_sparse(kern, X, y, Z, noise)
+
+    hip.set_option("stats_mode", mode)
+    try:
+        hip.set_data(X, y)
+        hip.set_inducing(Z)
+        set_kernel(hip, kern, noise)
+
+        lml = hip.sparse_lml()
+        ref = inf["log_marginal"][0, 0]
+        assert abs(lml - ref) <= 1e-10 * abs(ref), (lml, ref, hip.get("MODE", (1,)))
+        assert rel(hip.get("LM", (M, M)), inf["Lm"]) < 1e-9
+        assert rel(hip.get("A", (M, M)), inf["A"]) < 1e-8
+
+        lml2, dvar, dlen, dnoise, dZd = hip.sparse_lml_grad()
+        assert abs(lml2 - ref) <= 1e-10 * abs(ref)
+        gscale = max(abs(dn), max(abs(g[0]) for g in kg), max(np.abs(g[1]).max() for g in kg))
+        for p, (gv, gl) in enumerate(kg):
+            assert abs(dvar[p] - gv) <= 1e-7 * gscale, ("dvar", p, dvar[p], gv)
+            assert np.abs(fold_dlen(kern, dlen)[p] - gl).max() <= 1e-7 * gscale, ("dlen", p)
+        assert abs(dnoise - dn) <= 1e-7 * gscale, (dnoise, dn)
+        assert np.abs(dZd - dZ).max() <= 1e-6 * max(np.abs(dZ).max(), 1e-12), "dZ"
+
+        lml3 = hip.sparse_posterior()
+        assert abs(lml3 - ref) <= 1e-10 * abs(ref)
+        # woodbury factors are conditioning-sensitive (errors live in the small
+        # eigen-directions of Kmm); the posterior mean below is the pinned quantity
+        assert rel(hip.get("WV", (M,)), inf["woodbury_vector"][:, 0]) < 1e-5
+        assert rel(hip.get("WINV", (M, M)), inf["woodbury_inv"]) < 1e-3
+
+        rng = np.random.default_rng(1)
+        Xs = np.vstack([rng.standard_normal((40, D)), X[:8], Z[:5]])
+        mu_ref, var_ref = go.raw_predict(kern, Xs, Z, inf["woodbury_vector"], inf["woodbury_inv"])
+        jac_ref = go.predictive_gradients_mean(kern, Xs, Z, inf["woodbury_vector"])[:, :, 0]
+        mu, var = hip.predict(Xs)
+        assert rel(mu, mu_ref[:, 0]) < 1e-8
+        assert np.abs(var - var_ref[:, 0]).max() < 1e-7 * max(1.0, np.abs(var_ref).max())
+        jac = hip.predict_grad(Xs)
+        assert rel(jac, jac_ref) < 1e-8
+
+        mu_t, jac_t = hip.predict_train()
+        mu_tr, _ = go.raw_predict(kern, X, Z, inf["woodbury_vector"], inf["woodbury_inv"])
+        assert rel(mu_t, mu_tr[:, 0]) < 1e-8
+        assert rel(jac_t, go.predictive_gradients_mean(kern, X, Z, inf["woodbury_vector"])[:, :, 0]) < 1e-8
+    finally:
+        hip.set_option("stats_mode", 0)
+
+
+WELL_CONDITIONED = [c for i, c in enumerate(CASES) if i in (2, 3, 5, 6)]
+
+
+@pytest.mark.parametrize("N,M,D,kinds,opts,noise", WELL_CONDITIONED)
+def test_sparse_gram_form_statistics(hip, N, M, D, kinds, opts, noise):
+    """Gram form forced: Phi = K_mn K_nm and b = K_mn y are the all-reduced
+    statistics of the multi-GPU path; check them and the bound."""
+    X, y, Z = go.synthetic_problem(N, D, M, seed=N + M)
+    kern = go.make_kernel(kinds, D, opts)
+    hip.set_option("stats_mode", 1)
+    try:
+        hip.set_data(X, y)
+        hip.set_inducing(Z)
+        set_kernel(hip, kern, noise)
+        lml = hip.sparse_lml()
+        assert hip.get("MODE", (1,))[0] == 1.0
+        st = go.gram_stats(kern, X, Z, y[:, None])
+        assert rel(hip.get("PHI", (M, M)), st["Phi"]) < 1e-12
+        assert rel(hip.get("BVEC", (M,)), st["b"][:, 0]) < 1e-12
+        ref = go.vardtc_inference(kern, X, Z, noise, y[:, None])["log_marginal"][0, 0]
+        assert abs(lml - ref) <= 1e-10 * abs(ref)
+    finally:
+        hip.set_option("stats_mode", 0)
+
+
+def test_sparse_chunked_rows_equal_unchunked(hip):
+    N, M, D = 1500, 96, 7
+    X, y, Z = go.synthetic_problem(N, D, M, seed=3)
+    kern = go.make_kernel(["Matern52"], D, [dict(variance=1.2, lengthscale=2.2)])
+    hip.set_data(X, y)
+    hip.set_inducing(Z)
+    set_kernel(hip, kern, 0.03)
+    hip.set_option("chunk_rows", 131072)
+    a = hip.sparse_lml_grad()
+    hip.set_option("chunk_rows", 400)          # 4 ragged chunks
+    b = hip.sparse_lml_grad()
+    hip.set_option("chunk_rows", 131072)
+    inf, kg, dn, dZ = oracle_sparse(kern, X, y, Z, 0.03)
+    ref = inf["log_marginal"][0, 0]
+    for r in (a, b):
+        assert abs(r[0] - ref) <= 1e-10 * abs(ref)
+        assert abs(r[1][0] - kg[0][0]) <= 1e-7 * abs(kg[0][0])
+        assert np.abs(r[4] - dZ).max() <= 1e-7 * np.abs(dZ).max()
+
+
+def test_sparse_jitchol_retry_duplicate_inducing(hip):
+    """Z with exact duplicates: Kmm + 1e-8 I is numerically singular for a wide RBF;
+    the jitter ladder (GPy jitchol) must take over or succeed; result must be finite."""
+    N, M, D = 200, 24, 2
+    X, y, Z = go.synthetic_problem(N, D, M, seed=9)
+    Z[1] = Z[0]
+    Z[3] = Z[2]
+    kern = go.make_kernel(["RBF"], D, [dict(variance=1.0, lengthscale=30.0)])
+    hip.set_data(X, y)
+    hip.set_inducing(Z)
+    set_kernel(hip, kern, 0.1)
+    lml = hip.sparse_lml()
+    assert np.isfinite(lml)
+    ref = go.vardtc_inference(kern, X, Z, 0.1, y[:, None])["log_marginal"][0, 0]
+    assert abs(lml - ref) <= 1e-3 * abs(ref)      # ill-conditioned: loose, documented
+
+
+DENSE_CASES = [
+    (50, 1, ["RBF"], [dict(variance=1.0, lengthscale=1.0)], 1.0),
+    (300, 4, ["RBF"], [dict(variance=0.7, lengthscale=1.3)], 0.05),
+    (500, 2, ["Matern52"], [dict(variance=1.5, lengthscale=0.9)], 0.1),
+    (333, 5, ["RBF"], [dict(variance=0.7, lengthscale=[0.5, 1.0, 2.0, 4.0, 1.5], ARD=True)], 0.02),
+    (260, 3, ["Matern32", "RBF"], [dict(variance=0.5, lengthscale=1.0), dict(variance=0.4, lengthscale=3.0)], 0.05),
+]
+
+
+@pytest.mark.parametrize("N,D,kinds,opts,noise", DENSE_CASES)
+def test_dense_lml_gradients_predict(hip, N, D, kinds, opts, noise):
+    X, y, _ = go.synthetic_problem(N, D, 4, seed=N)
+    kern = go.make_kernel(kinds, D, opts)
+    inf = go.exact_inference(kern, X, noise, y[:, None])
+    kg, dn = go.dense_gradients(kern, X, inf)
+    hip.set_data(X, y)
+    set_kernel(hip, kern, noise)
+    assert abs(hip.dense_lml() - inf["log_marginal"]) <= 1e-10 * abs(inf["log_marginal"])
+    lml, dvar, dlen, dnoise = hip.dense_lml_grad()
+    assert abs(lml - inf["log_marginal"]) <= 1e-10 * abs(inf["log_marginal"])
+    gscale = max(abs(dn), max(abs(g[0]) for g in kg), max(np.abs(g[1]).max() for g in kg))
+    for p, (gv, gl) in enumerate(kg):
+        assert abs(dvar[p] - gv) <= 1e-8 * gscale
+        assert np.abs(fold_dlen(kern, dlen)[p] - gl).max() <= 1e-8 * gscale
+    assert abs(dnoise - dn) <= 1e-8 * gscale
+    hip.dense_posterior()
+    rng = np.random.default_rng(2)
+    Xs = np.vstack([rng.standard_normal((30, D)), X[:6]])
+    mu_ref, var_ref = go.raw_predict(kern, Xs, X, inf["woodbury_vector"], inf["woodbury_inv"])
+    jac_ref = go.predictive_gradients_mean(kern, Xs, X, inf["woodbury_vector"])[:, :, 0]
+    mu, var = hip.predict(Xs)
+    assert rel(mu, mu_ref[:, 0]) < 1e-8
+    assert np.abs(var - var_ref[:, 0]).max() < 1e-8 * max(1.0, np.abs(var_ref).max())
+    assert rel(hip.predict_grad(Xs), jac_ref) < 1e-8
