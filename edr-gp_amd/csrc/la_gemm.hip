@@ -270,7 +270,7 @@ static int gemm_impl(Ctx* c, bool transA, bool transB, int M, int N, int K, doub
     g.tiles_n = (N + tile - 1) / tile;
     g.vecA = aligned16(A) && (lda % 2 == 0) && (o.strideA % 2 == 0);
     g.vecB = aligned16(B) && (ldb % 2 == 0) && (o.strideB % 2 == 0);
-    if (splits > 1) {
+    if (slab != nullptr) {
         g.C = slab; g.ldc = slab_ld; g.alpha = 1.0; g.beta = 0.0; g.slabStride = slabStride;
     } else {
         g.C = C; g.ldc = ldc; g.alpha = alpha; g.beta = beta; g.slabStride = 0;
