@@ -16,84 +16,118 @@ namespace edrgp {
 
 constexpr int NB = 64;
 
-// Factor (do_chol) and/or invert one 64x64 lower block per workgroup (64 threads
-// = one wave).  A is the block origin; jb <= 64 valid rows/cols, the rest is
-// padded with the identity inside LDS.  Writes L (lower, zeros above) back when
-// do_chol, and the inverse to Dinv (64x64 dense, row-major, ld 64) or, when
-// inv_out != nullptr, into the matrix inv_out (ld ldi) restricted to jb x jb.
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+
+// sqrt(p) and 1/sqrt(p) by Goldschmidt iteration from v_rsq_f64 (p > 0, normal
+// range): two coupled refinements + one residual correction, ~1 ulp.
+__device__ __forceinline__ void sqrt_rsqrt(double p, double& sq, double& rs) {
+    const double y = __builtin_amdgcn_rsq(p);
+    double g = p * y, h = 0.5 * y;
+    double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    const double d = fma(-g, g, p);
+    sq = fma(d, h, g);
+    rs = h + h;
+}
+
+// Factor (DO_CHOL) and invert one 64x64 lower block per workgroup; the
+// workgroup is ONE wave and lane i owns row i of the block in registers.
+//   factor : right-looking, fully unrolled.  Column j: pivot broadcast by
+//            v_readlane, Goldschmidt rsqrt, the finished column goes to LDS
+//            (Lt[j][*], lane-contiguous) and is read back as wave-uniform
+//            broadcasts for the rank-1 update of the lane's row.
+//   invert : lane c solves L x = e_c by forward substitution, L read from Lt as
+//            broadcasts, x in registers, no cross-lane traffic.
+// jb <= 64 valid rows/cols; the rest is padded with the identity.  Outputs: L
+// (lower, zeros above) written back when DO_CHOL; the inverse goes to Dinv
+// (dense 64x64, ld 64) and/or into inv_out (ld ldi, jb x jb part).
+template <bool DO_CHOL>
 __global__ __launch_bounds__(64) void diag_block_kernel(double* __restrict__ Abase, int lda, int n,
-                                                        int first_block, int do_chol,
-                                                        double* __restrict__ Dinv,
+                                                        int first_block, double* __restrict__ Dinv,
                                                         double* __restrict__ inv_out, int ldi,
                                                         int* __restrict__ info) {
-    __shared__ double S[NB][NB + 1];
-    __shared__ double Xi[NB][NB + 1];
+    __shared__ double Lt[NB][NB + 1];      // Lt[k][i] = L[i][k]
+    __shared__ double rdiag[NB];           // 1 / L[i][i]
     const int lane = threadIdx.x;
     const int blk = first_block + blockIdx.x;
     const int j0 = blk * NB;
     const int jb = min(NB, n - j0);
     double* A = Abase + (size_t)j0 * lda + j0;
 
+    // coalesced load of the block, transposed into LDS: Lt[c][r] = A[r][c]
     for (int r = 0; r < NB; ++r) {
         double v = (r == lane) ? 1.0 : 0.0;
         if (r < jb && lane < jb && lane <= r) v = A[(size_t)r * lda + lane];
-        S[r][lane] = v;
-        Xi[r][lane] = 0.0;
+        Lt[lane][r] = v;
     }
     __syncthreads();
 
-    if (do_chol) {
-        const int i = lane;
+    if (DO_CHOL) {
+        double a[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) a[k] = Lt[k][lane];      // row `lane`
+        __syncthreads();
         int bad = 0;
+#pragma unroll
         for (int j = 0; j < NB; ++j) {
-            double s = S[i][j];
-            int k = 0;
-            for (; k + 4 <= j; k += 4) {
-                s -= S[i][k] * S[j][k];
-                s -= S[i][k + 1] * S[j][k + 1];
-                s -= S[i][k + 2] * S[j][k + 2];
-                s -= S[i][k + 3] * S[j][k + 3];
-            }
-            for (; k < j; ++k) s -= S[i][k] * S[j][k];
-            const double d = __shfl(s, j, 64);
-            if (!(d > 0.0) && bad == 0) bad = j0 + j + 1;
-            const double dd = sqrt(d);               // NaN propagates when d <= 0
+            const double p = readlane_f64(a[j], j);
+            if (!(p > 0.0) && bad == 0) bad = j0 + j + 1;
+            double sq, rs;
+            sqrt_rsqrt(p, sq, rs);
+            double l = a[j] * rs;
+            if (lane == j) l = sq;
+            if (lane < j) l = 0.0;
+            a[j] = l;
+            Lt[j][lane] = l;
+            if (lane == j) rdiag[j] = rs;
             __syncthreads();
-            if (i == j) S[i][j] = dd;
-            else if (i > j) S[i][j] = s / dd;
-            __syncthreads();
+#pragma unroll
+            for (int k = j + 1; k < NB; ++k) a[k] = fma(-l, Lt[j][k], a[k]);
         }
-        if (bad && lane == 0) atomicCAS(info, 0, bad);
-        // write L back (lower part, zeros above inside the block)
+        if (bad && lane == 0 && info != nullptr) atomicCAS(info, 0, bad);
+        __syncthreads();
+        // coalesced write-back of L (lower part, explicit zeros above)
         for (int r = 0; r < jb; ++r)
-            if (lane < jb) A[(size_t)r * lda + lane] = (lane <= r) ? S[r][lane] : 0.0;
+            if (lane < jb) A[(size_t)r * lda + lane] = (lane <= r) ? Lt[lane][r] : 0.0;
+    } else {
+        rdiag[lane] = 1.0 / Lt[lane][lane];
+        __syncthreads();
     }
 
-    // inverse by forward substitution, lane c owns column c of the inverse
+    // inverse: lane c owns column c
     {
-        const int cidx = lane;
+        double x[NB];
+#pragma unroll
         for (int i = 0; i < NB; ++i) {
-            double s = (i == cidx) ? 1.0 : 0.0;
-            int k = 0;
-            for (; k + 4 <= i; k += 4) {
-                s -= S[i][k] * Xi[k][cidx];
-                s -= S[i][k + 1] * Xi[k + 1][cidx];
-                s -= S[i][k + 2] * Xi[k + 2][cidx];
-                s -= S[i][k + 3] * Xi[k + 3][cidx];
+            double s0 = (i == lane) ? 1.0 : 0.0, s1 = 0.0;
+#pragma unroll
+            for (int k = 0; k + 1 < i; k += 2) {
+                s0 = fma(-Lt[k][i], x[k], s0);
+                s1 = fma(-Lt[k + 1][i], x[k + 1], s1);
             }
-            for (; k < i; ++k) s -= S[i][k] * Xi[k][cidx];
-            Xi[i][cidx] = s / S[i][i];
-            __syncthreads();
+            if (i & 1) s0 = fma(-Lt[i - 1][i], x[i - 1], s0);
+            x[i] = (s0 + s1) * rdiag[i];
         }
-    }
-    if (Dinv) {
-        double* D = Dinv + (size_t)blockIdx.x * NB * NB;
-        for (int r = 0; r < NB; ++r) D[r * NB + lane] = Xi[r][lane];
-    }
-    if (inv_out) {
-        double* O = inv_out + (size_t)j0 * ldi + j0;
-        for (int r = 0; r < jb; ++r)
-            if (lane < jb) O[(size_t)r * ldi + lane] = Xi[r][lane];
+        if (Dinv) {
+            double* D = Dinv + (size_t)blockIdx.x * NB * NB;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) D[i * NB + lane] = x[i];
+        }
+        if (inv_out) {
+            double* O = inv_out + (size_t)j0 * ldi + j0;
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                if (i < jb && lane < jb) O[(size_t)i * ldi + lane] = x[i];
+        }
     }
 }
 
@@ -119,28 +153,27 @@ __global__ void fill_kernel(double* __restrict__ A, size_t count, double v) {
 int potrf_lower(Ctx* c, double* A, int n, int lda, int* info_dev) {
     HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), c->stream));
     TRY(c->dinv.reserve((size_t)NB * NB * sizeof(double)));
-    TRY(c->panel.reserve((size_t)n * NB * sizeof(double)));
     double* Dinv = c->dinv.d();
-    double* P = c->panel.d();
     const int nblk = (n + NB - 1) / NB;
     for (int b = 0; b < nblk; ++b) {
         const int j0 = b * NB;
         const int jb = std::min(NB, n - j0);
-        hipLaunchKernelGGL(diag_block_kernel, dim3(1), dim3(64), 0, c->stream, A, lda, n, b, 1, Dinv,
+        hipLaunchKernelGGL(diag_block_kernel<true>, dim3(1), dim3(64), 0, c->stream, A, lda, n, b, Dinv,
                            (double*)nullptr, 0, info_dev);
         const int rem = n - j0 - jb;
         if (rem > 0) {
             double* A21 = A + (size_t)(j0 + jb) * lda + j0;
-            // P = A21 * Dinv^T   (rem x jb), Dinv is 64x64 with identity padding
-            TRY(gemm(c, false, true, rem, jb, jb, 1.0, A21, lda, Dinv, NB, 0.0, P, NB));
-            dim3 blk(64, 4), grd((jb + 63) / 64, (rem + 3) / 4);
-            hipLaunchKernelGGL(copy2d_kernel, grd, blk, 0, c->stream, P, NB, A21, lda, rem, jb);
-            // A22 -= P P^T on the lower tiles
+            // L21 = A21 * Dinv^T in place: a workgroup owns whole rows of the 64-wide
+            // panel (one column tile) and has consumed them before its epilogue stores.
+            GemmOpts po;
+            po.force_tile = 64;
+            TRY(gemm(c, false, true, rem, jb, jb, 1.0, A21, lda, Dinv, NB, 0.0, A21, lda, po));
+            // A22 -= L21 L21^T on the lower tiles
             double* A22 = A + (size_t)(j0 + jb) * lda + (j0 + jb);
             GemmOpts o;
             o.tri = 1;
             o.force_tile = (rem >= 1024) ? 128 : 64;
-            TRY(gemm(c, false, true, rem, rem, jb, -1.0, P, NB, P, NB, 1.0, A22, lda, o));
+            TRY(gemm(c, false, true, rem, rem, jb, -1.0, A21, lda, A21, lda, 1.0, A22, lda, o));
         }
     }
     dim3 blk(64, 4), grd((n + 63) / 64, (n + 3) / 4);
@@ -161,8 +194,8 @@ int trtri_lower(Ctx* c, const double* L, int ldl, double* Linv, int ldi, int n) 
         }
     }
     const int nblk = (n + NB - 1) / NB;
-    hipLaunchKernelGGL(diag_block_kernel, dim3(nblk), dim3(64), 0, c->stream, const_cast<double*>(L), ldl, n,
-                       0, 0, (double*)nullptr, Linv, ldi, (int*)nullptr);
+    hipLaunchKernelGGL(diag_block_kernel<false>, dim3(nblk), dim3(64), 0, c->stream, const_cast<double*>(L), ldl,
+                       n, 0, (double*)nullptr, Linv, ldi, (int*)nullptr);
     HIP_TRY(hipGetLastError());
     if (n <= NB) return EDRGP_OK;
     TRY(c->trtri_ws.reserve((size_t)n * n * sizeof(double)));
