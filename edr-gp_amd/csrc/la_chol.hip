@@ -63,11 +63,17 @@ __global__ __launch_bounds__(64) void diag_block_kernel(double* __restrict__ Aba
     const int jb = min(NB, n - j0);
     double* A = Abase + (size_t)j0 * lda + j0;
 
-    // coalesced load of the block, transposed into LDS: Lt[c][r] = A[r][c]
-    for (int r = 0; r < NB; ++r) {
-        double v = (r == lane) ? 1.0 : 0.0;
-        if (r < jb && lane < jb && lane <= r) v = A[(size_t)r * lda + lane];
-        Lt[lane][r] = v;
+    // coalesced load of the block (all 64 row loads in flight at once), then
+    // transposed into LDS: Lt[c][r] = A[r][c]
+    {
+        double t[NB];
+#pragma unroll
+        for (int r = 0; r < NB; ++r) {
+            t[r] = (r == lane) ? 1.0 : 0.0;
+            if (r < jb && lane < jb && lane <= r) t[r] = A[(size_t)r * lda + lane];
+        }
+#pragma unroll
+        for (int r = 0; r < NB; ++r) Lt[lane][r] = t[r];
     }
     __syncthreads();
 

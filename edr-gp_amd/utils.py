@@ -1,0 +1,74 @@
+"""Subspace helpers used by the EDR estimators (API of ``edrgp.utils``:
+edrgp/utils.py:8-175).  Small dense linear algebra on the (N x D) gradient
+matrix; stays on the host."""
+from __future__ import annotations
+
+import numpy as np
+import scipy.linalg
+from sklearn.base import BaseEstimator, TransformerMixin
+from sklearn.utils import check_array
+
+
+def ort_space(A):
+    """Orthonormal basis (columns) of the orthogonal complement of span(A),
+    A is [n_features, n_components] (edrgp/utils.py:8-24)."""
+    U, s, _ = scipy.linalg.svd(A, full_matrices=True)
+    rank = int(np.sum(np.abs(s) > 1e-10))
+    return U[:, rank:]
+
+
+def subspace_variance_ratio(X, V):
+    """Norm of X projected on the columns of V, and its squared share of ||X||_F.
+    Per column when V is orthonormal, otherwise one number for span(V)
+    (edrgp/utils.py:27-55)."""
+    gram = V.T @ V
+    if np.allclose(gram, np.eye(V.shape[1])):
+        proj = np.linalg.norm(X @ V, axis=0)
+    else:
+        Q = np.linalg.qr(V)[0]
+        proj = np.linalg.norm(X @ Q)
+    return proj, (proj / np.linalg.norm(X)) ** 2
+
+
+def discrepancy(B, V):
+    """||B B^T (I - V V^T)||_F / d, d = number of true components (edrgp/utils.py:58-78)."""
+    residual = np.eye(B.shape[0]) - V @ V.T
+    return np.linalg.norm((B @ B.T) @ residual) / B.shape[1]
+
+
+class SVDTransformer(BaseEstimator, TransformerMixin):
+    """PCA without centring or scaling: right singular vectors of the data
+    (edrgp/utils.py:81-175).
+
+    n_components : None (all), int, or float in (0, 1) = smallest number of
+    components whose cumulative variance share reaches that value.
+
+    Attributes: components_ (n_components, n_features), subspace_variance_,
+    subspace_variance_ratio_.
+    """
+
+    def __init__(self, n_components=None):
+        self.n_components = n_components
+
+    def fit(self, X, y=None):
+        Xc = check_array(X, copy=True)
+        _, S, Vh = np.linalg.svd(Xc)
+        var = S ** 2
+        ratio = var / var.sum()
+        k = Xc.shape[1]
+        nc = self.n_components
+        if isinstance(nc, (int, np.integer)) and not isinstance(nc, bool) and 0 < nc <= Xc.shape[1]:
+            k = int(nc)
+        elif isinstance(nc, float) and 0 < nc < 1:
+            # (the reference raises NameError here: undefined `expl_var_ratio`, utils.py:148-150)
+            k = int(np.sum(np.cumsum(ratio) < nc)) + 1
+        elif nc is True:
+            k = 1                      # examples/regression.py passes True positionally
+        k = min(Xc.shape[0], k)
+        self.components_ = Vh[:k, :]
+        self.subspace_variance_ = var[:k]
+        self.subspace_variance_ratio_ = ratio[:k]
+        return self
+
+    def transform(self, X):
+        return np.asarray(X).dot(self.components_.T)

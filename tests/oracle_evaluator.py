@@ -1,0 +1,62 @@
+"""Test-only evaluator: answers the model layer's device calls with the CPU oracle,
+so the host logic (parameter packing, Logexp, L-BFGS-B driver, normaliser, EDR loop)
+can be exercised without a GPU.  Never imported by the product."""
+import numpy as np
+
+from oracle import gp_oracle as go
+
+
+class OracleEvaluator:
+    def _kern(self, model):
+        D = model.input_dim
+        return go.Add([go.Stationary(p.kind, D, p.variance, p.lengthscale.copy(), p.ARD) for p in model.kern.parts])
+
+    def _expand(self, kern, kg):
+        D = kern.input_dim
+        dvar = np.array([g[0] for g in kg])
+        dlen = np.zeros((len(kg), D))
+        for i, (g, part) in enumerate(zip(kg, kern.parts)):
+            if part.ARD:
+                dlen[i] = g[1]
+            else:
+                dlen[i, 0] = g[1][0]       # the model sums the row for an isotropic part
+        return dvar, dlen
+
+    def lml(self, model):
+        k = self._kern(model)
+        if model.is_sparse:
+            return go.vardtc_inference(k, model.X, model.Z, model.noise_variance, model.Y_normalized)["log_marginal"][0, 0]
+        return go.exact_inference(k, model.X, model.noise_variance, model.Y_normalized)["log_marginal"]
+
+    def lml_grad(self, model):
+        k = self._kern(model)
+        if model.is_sparse:
+            inf = go.vardtc_inference(k, model.X, model.Z, model.noise_variance, model.Y_normalized)
+            kg, dn, dZ = go.sparse_gradients(k, model.X, model.Z, inf)
+            dvar, dlen = self._expand(k, kg)
+            return inf["log_marginal"][0, 0], dvar, dlen, dn, dZ
+        inf = go.exact_inference(k, model.X, model.noise_variance, model.Y_normalized)
+        kg, dn = go.dense_gradients(k, model.X, inf)
+        dvar, dlen = self._expand(k, kg)
+        return inf["log_marginal"], dvar, dlen, dn, None
+
+    def _post(self, model):
+        k = self._kern(model)
+        if model.is_sparse:
+            inf = go.vardtc_inference(k, model.X, model.Z, model.noise_variance, model.Y_normalized)
+            return k, model.Z, inf["woodbury_vector"], inf["woodbury_inv"]
+        inf = go.exact_inference(k, model.X, model.noise_variance, model.Y_normalized)
+        return k, model.X, inf["woodbury_vector"], inf["woodbury_inv"]
+
+    def predict(self, model, Xs, want_var=True):
+        k, P, wv, winv = self._post(model)
+        mu, var = go.raw_predict(k, Xs, P, wv, winv)
+        return mu[:, 0], (var[:, 0] if want_var else None)
+
+    def predict_grad(self, model, Xs):
+        k, P, wv, _ = self._post(model)
+        return go.predictive_gradients_mean(k, Xs, P, wv)[:, :, 0]
+
+    def predict_train(self, model, want_mean=True, want_grad=True):
+        mu = self.predict(model, model.X, False)[0] if want_mean else None
+        return mu, (self.predict_grad(model, model.X) if want_grad else None)
