@@ -90,9 +90,18 @@ class HipEvaluator:
 
     def __init__(self, device=None):
         from .device import shared_context
+        self._device = device
         self._ctx = shared_context(device)
         self._token = next(_token_counter)
         self._sent = {}
+
+    # a copied / unpickled model gets a fresh binding to the shared context
+    # (native handles are never copied)
+    def __deepcopy__(self, memo):
+        return HipEvaluator(self._device)
+
+    def __reduce__(self):
+        return (HipEvaluator, (self._device,))
 
     @property
     def hip(self):

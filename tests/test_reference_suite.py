@@ -112,7 +112,10 @@ def test_iterative_edr_recovers_subspace(n_components, step):
                                            PCA(), n_components, step, True)
     edr.fit(X, y)
     comps = edr.components_ / np.linalg.norm(edr.components_, axis=1, keepdims=True)
-    Q = np.linalg.qr(comps[:3].T)[0]
+    if n_components is not None:
+        assert comps.shape[0] == n_components        # directions were dropped down to the target
+    assert np.all(edr.subspace_variance_ratio_ == np.sort(edr.subspace_variance_ratio_)[::-1])
+    Q = np.linalg.qr(comps.T)[0]                     # span of every kept direction
     assert discrepancy(B, Q) < 0.2
 
 
