@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Headline benchmark: sparse-GP fit+predict throughput on MI355X.
+
+Metric (BASELINE.json): "GP fit+predict throughput (points/sec) and log-ml
+evals/sec at N=100k, M=2048; 1/2/4/8 GPU".  Workload = SURVEY.md section 8(d) "Cm":
+N = 100,000 rows per GPU, M = 2048 inducing points, D = 32, RBF, fp64,
+sigma_f^2 = 1, l = sqrt(D), sigma_n^2 = 0.01, synthetic tanh data.
+
+One *step* = one fit+predict pass of the hot path over the resident batch:
+  50 bound+gradient evaluations (the L-BFGS-B hot loop of `fit`,
+  edrgp/gp_model/base.py:69, at a fixed iteration count and along a
+  deterministic hyper-parameter path; every evaluation re-sends theta and Z and
+  fetches the gradients, as the optimiser does)
+  + posterior build + predict and predict_gradient on the N training points
+  (edrgp/base.py:274).
+value = points processed by all ranks per second = n_gpus * N * steps / time.
+Inputs are resident in HBM before the timed region starts.  With N > 1 ranks the
+rows are sharded (weak scaling: N per GPU fixed) and Phi / K_mn y / gradient
+partials are sum-all-reduced over RCCL once per evaluation.
+
+The same JSON line carries the log-ml evals/sec figure, the roofline of the
+dominant kernel (the fp64 MFMA syrk Phi = K_mn K_nm, timed with HIP events on the
+library's stream inside the timed region) and a CPU baseline (the numpy/scipy
+oracle, i.e. GPy's operation sequence, on a bounded row sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_SPEC_TFLOPS = 78.6      # AMD public MI355X fp64 matrix peak; the local guide lists none
+ITERS_PER_FIT = 50
+
+
+def synthetic(N, D, M, seed, z_seed=0):
+    """X ~ N(0, I); y = tanh(X w) + 0.05 eps standardised; Z = first-shard rows."""
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((N, D))
+    y = np.tanh(X @ (np.ones(D) / np.sqrt(D))) + 0.05 * rng.standard_normal(N)
+    y = (y - y.mean()) / y.std()
+    zr = np.random.default_rng(z_seed)
+    Xz = zr.standard_normal((max(N, M), D))          # identical on every rank
+    Z = Xz[zr.permutation(Xz.shape[0])[:M]].copy()
+    return X, y, Z
+
+
+def theta_path(i, D, kind):
+    """Deterministic hyper-parameter / inducing-input path standing in for optimiser iterates."""
+    s = 1.0 + 1e-3 * ((i % 7) - 3)
+    return dict(variance=1.0 * s, lengthscale=np.sqrt(D) * s, noise=0.01 * s)
+
+
+def fit_predict_step(h, Z, D, kind, iters):
+    for i in range(iters):
+        th = theta_path(i, D, kind)
+        h.set_inducing(Z)
+        h.set_kernel([kind], [th["variance"]], np.full((1, D), th["lengthscale"]), th["noise"])
+        h.sparse_lml_grad()
+    h.sparse_posterior()
+    h.predict_train(want_mean=True, want_grad=True)
+
+
+def cpu_baseline(N_sample, M, D, kind, iters):
+    """The CPU path timed beside the GPU one: the oracle (GPy's LAPACK/BLAS call
+    sequence restated in numpy/scipy) on a bounded row sample, all host cores."""
+    from oracle import gp_oracle as go
+    X, y, Z = synthetic(N_sample, D, M, seed=123)
+    kern = go.make_kernel([kind], D, [dict(variance=1.0, lengthscale=np.sqrt(D))])
+    Y = y[:, None]
+    t0 = time.perf_counter()
+    inf = go.vardtc_inference(kern, X, Z, 0.01, Y)
+    go.sparse_gradients(kern, X, Z, inf)
+    t_eval = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    go.vardtc_inference(kern, X, Z, 0.01, Y)
+    t_lml = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    go.raw_predict(kern, X, Z, inf["woodbury_vector"], inf["woodbury_inv"])
+    go.predictive_gradients_mean(kern, X, Z, inf["woodbury_vector"])
+    t_pred = time.perf_counter() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    step_time = iters * t_eval + t_lml + t_pred
+    return {
+        "value": N_sample / step_time, "unit": "points/s", "cores": int(threads), "kind": "port",
+        "sample": "%d of the %d rows, M=%d D=%d; one bound+gradient evaluation (%.2f s), one bound (%.2f s) and one "
+                  "predict+predict_gradient pass (%.2f s) timed, step time = %d x eval + bound + predict; "
+                  "log-ml evals/s on the sample: %.3f" % (N_sample, 100000, M, D, t_eval, t_lml, t_pred, iters, 1.0 / t_lml),
+        "lml_evals_per_sec_sample": 1.0 / t_lml,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--N", type=int, default=100000, help="rows per GPU")
+    ap.add_argument("--M", type=int, default=2048)
+    ap.add_argument("--D", type=int, default=32)
+    ap.add_argument("--kind", default="RBF")
+    ap.add_argument("--iters", type=int, default=ITERS_PER_FIT)
+    ap.add_argument("--cpu-sample", type=int, default=4000, help="rows of the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from edrgp_amd.backend import HipGP
+    h = HipGP(local_rank)                      # raises without a gfx950 device: no CPU fallback
+    if world > 1:
+        box = [HipGP.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        h.comm_init(world, rank, box[0])
+
+    N, M, D = args.N, args.M, args.D
+    X, y, Z = synthetic(N, D, M, seed=1000 + rank)
+    h.set_data(X, y)                           # resident in HBM from here on
+    h.set_inducing(Z)
+    h.set_kernel([args.kind], [1.0], np.full((1, D), np.sqrt(D)), 0.01)
+
+    def barrier_sync():
+        h.sync()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        fit_predict_step(h, Z, D, args.kind, args.iters)
+    h.set_option("profile", 1)
+    h.profile_reset()
+    barrier_sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fit_predict_step(h, Z, D, args.kind, args.iters)
+    barrier_sync()
+    elapsed = time.perf_counter() - t0
+    syrk_ms, syrk_n = h.profile_get("SYRK")
+    grad_ms, grad_n = h.profile_get("GRADGEMM")
+    kb_ms, kb_n = h.profile_get("KBUILD")
+    small_ms, _ = h.profile_get("SMALL")
+    h.set_option("profile", 0)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # log-ml evals/sec (second half of the metric): bound-only evaluations, same resident data
+    n_lml = 20
+    h.set_kernel([args.kind], [1.0], np.full((1, D), np.sqrt(D)), 0.01)
+    h.sparse_lml()
+    barrier_sync()
+    t1 = time.perf_counter()
+    for _ in range(n_lml):
+        h.sparse_lml()
+    barrier_sync()
+    lml_elapsed = time.perf_counter() - t1
+    if dist is not None:
+        t = torch.tensor([lml_elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        lml_elapsed = float(t.item())
+    mode = int(h.get("MODE", (1,))[0])
+
+    if rank == 0:
+        value = world * N * args.steps / elapsed
+        flops_per_launch = float(N) * M * (M + 1.0)                 # syrk, lower triangle only
+        avg_ms = syrk_ms / max(syrk_n, 1)
+        achieved = flops_per_launch / (avg_ms * 1e-3) * 1e-12 if syrk_n else None
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_syrk.json")
+        if os.path.exists(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        calib_tf = None
+        try:
+            calib_tf, _ = h.calib()
+        except Exception:
+            pass
+        out = {
+            "metric": "GP fit+predict throughput (points/sec) at N=100k,M=2048 per GPU; log-ml evals/sec alongside",
+            "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Cm: inducing-point sparse GP (VarDTC), N=%d rows per GPU, M=%d, D=%d, %s, fp64; "
+                                   "step = %d bound+gradient evaluations + posterior + predict/predict_gradient on N rows"
+                                   % (N, M, D, args.kind, args.iters),
+                       "N_per_gpu": N, "M": M, "D": D, "kernel": args.kind, "evals_per_step": args.iters,
+                       "sharding": "rows; one RCCL sum-all-reduce of Phi|K_mn y and of gradient partials per evaluation"
+                       if world > 1 else "single GPU", "stats_form": {1: "gram", 2: "stable"}.get(mode, "?")},
+            "lml_evals_per_sec": n_lml / lml_elapsed,
+            "lml_grad_evals_per_sec": args.steps * args.iters / elapsed,
+            "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel<128,128,true,true,1> (Phi = K_mn K_nm, fp64 MFMA syrk)",
+                         "achieved": achieved, "peak": FP64_MFMA_SPEC_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (achieved / FP64_MFMA_SPEC_TFLOPS) if achieved else None, "traffic": traffic,
+                         "avg_launch_ms": avg_ms, "launches": syrk_n, "flops_per_launch": flops_per_launch,
+                         "peak_source": "AMD public MI355X fp64 matrix spec (not in the local guide)",
+                         "peak_calibrated_tflops": calib_tf},
+            "device_ms_per_step": {"syrk": syrk_ms / args.steps, "grad_gemm": grad_ms / args.steps,
+                                   "kernel_build": kb_ms / args.steps, "small_MxM": small_ms / args.steps},
+        }
+        if args.cpu_sample > 0 and world == 1:        # rank 0 at N=1 only
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, M, D, args.kind, args.iters)
+        print(json.dumps(out))
+    if world > 1:
+        h.comm_destroy()
+        dist.destroy_process_group()
+    h.close()
+
+
+if __name__ == "__main__":
+    main()
