@@ -91,6 +91,10 @@ def cpu_baseline(N_sample, M, D, kind, iters):
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
     except Exception:
         threads = os.cpu_count() or 1
+    try:
+        threads = min(threads, len(os.sched_getaffinity(0)))      # BLAS threads that can actually run
+    except AttributeError:
+        pass
     step_time = iters * t_eval + t_lml + t_pred
     return {
         "value": N_sample / step_time, "unit": "points/s", "cores": int(threads), "kind": "port",

@@ -324,7 +324,10 @@ int syrk_tn(Ctx* c, const double* K, int64_t rows, int M, int ldk, double* Phi, 
     const int kt = (int)((rows + BK - 1) / BK);
     int splits = c->syrk_splits;
     if (splits <= 0) {
-        splits = (int)((2048 + nt - 1) / nt);
+        // 2 workgroups per CU are resident: fill whole rounds of 2 * num_cu
+        // workgroups (4 rounds) and never start a nearly empty extra round.
+        const long long slots = 2LL * c->num_cu;
+        splits = (int)std::max<long long>(1, (4 * slots) / nt);
         const int max_splits = std::max(1, kt / 16);          // >= 256 rows per split
         if (splits > max_splits) splits = max_splits;
     }

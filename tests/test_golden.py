@@ -1,0 +1,140 @@
+"""Golden-vector tests.
+
+gp_golden.npz  : oracle outputs cross-checked with scikit-learn at generation
+                 time (tests/golden/make_gp_golden.py).  CPU: the oracle still
+                 reproduces them (and the sklearn known answers stored inside).
+                 GPU: the HIP path reproduces them.
+edr_golden.npz : outputs of the REFERENCE's EDR layer on a deterministic duck
+                 estimator (tests/golden/make_edr_golden.py).  CPU: this
+                 repo's EDR classes reproduce them.
+"""
+import os
+
+import numpy as np
+import pytest
+from sklearn.decomposition import PCA
+
+from oracle import gp_oracle as go
+from duck_estimator import TanhRidgeEstimator
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gp_cases():
+    f = np.load(os.path.join(GOLD, "gp_golden.npz"), allow_pickle=False)
+    for i in range(int(f["n_cases"])):
+        p = "c%02d_" % i
+        yield {k[len(p):]: f[k] for k in f.files if k.startswith(p)}
+
+
+GP_CASES = list(gp_cases())
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.mark.parametrize("c", GP_CASES, ids=lambda c: "%s-N%d-s%d" % (str(c["kind"]), c["meta"][1], c["meta"][0]))
+def test_oracle_reproduces_golden(c):
+    seed, N, M, D = (int(v) for v in c["meta"])
+    var, ls, noise = c["theta"]
+    kern = go.make_kernel([str(c["kind"])], D, [dict(variance=var, lengthscale=ls)])
+    inf = go.vardtc_inference(kern, c["X"], c["Z"], noise, c["y"][:, None])
+    assert rel(inf["log_marginal"], c["bound"]) < 1e-12
+    kg, dn, dZ = go.sparse_gradients(kern, c["X"], c["Z"], inf)
+    assert rel([kg[0][0], kg[0][1][0], dn], c["grad"]) < 1e-9
+    mu, _ = go.raw_predict(kern, c["Xs"], c["Z"], inf["woodbury_vector"], inf["woodbury_inv"])
+    assert rel(mu[:, 0], c["pred_mean"]) < 1e-9
+    dense = go.exact_inference(kern, c["X"], noise, c["y"][:, None])
+    # c["dense_lml"][1] is scikit-learn's independent value
+    assert abs(dense["log_marginal"] - c["dense_lml"][1]) < 1e-9 * abs(c["dense_lml"][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", GP_CASES, ids=lambda c: "%s-N%d-s%d" % (str(c["kind"]), c["meta"][1], c["meta"][0]))
+def test_hip_reproduces_golden(hip, c):
+    seed, N, M, D = (int(v) for v in c["meta"])
+    var, ls, noise = c["theta"]
+    kind = str(c["kind"])
+    hip.set_data(c["X"], c["y"])
+    hip.set_inducing(c["Z"])
+    hip.set_kernel([kind], [var], np.full((1, D), ls), noise)
+    lml, dvar, dlen, dnoise, dZ = hip.sparse_lml_grad()
+    assert abs(lml - c["bound"][0, 0]) <= 1e-10 * abs(c["bound"][0, 0])
+    g = np.array([dvar[0], dlen[0].sum(), dnoise])
+    assert np.abs(g - c["grad"]).max() <= 1e-7 * np.abs(c["grad"]).max()
+    assert np.abs(dZ - c["dZ"]).max() <= 1e-6 * np.abs(c["dZ"]).max()
+    hip.sparse_posterior()
+    mu, v = hip.predict(c["Xs"])
+    assert rel(mu, c["pred_mean"]) < 1e-8
+    assert np.abs(v - c["pred_var"]).max() < 1e-7
+    assert rel(hip.predict_grad(c["Xs"]), c["pred_jac"]) < 1e-8
+    # dense exact GP on the same data: sklearn's LML is the independent known answer
+    lml_d, dv_d, dl_d, dn_d = hip.dense_lml_grad()
+    assert abs(lml_d - c["dense_lml"][1]) <= 1e-9 * abs(c["dense_lml"][1])
+    gd = np.array([dv_d[0], dl_d[0].sum(), dn_d])
+    assert np.abs(gd - c["dense_grad"]).max() <= 1e-8 * np.abs(c["dense_grad"]).max()
+    hip.dense_posterior()
+    mu, v = hip.predict(c["Xs"])
+    assert rel(mu, c["dense_pred_mean"]) < 1e-8
+    assert np.abs(v - c["dense_pred_var"]).max() < 1e-7
+
+
+# ---------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def edr_gold():
+    return np.load(os.path.join(GOLD, "edr_golden.npz"), allow_pickle=False)
+
+
+def close(a, b, tol=1e-9):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max())
+
+
+@pytest.mark.parametrize("name,cfg", [
+    ("oneshot", dict(n_components=2, step=None, normalize=True, preprocessor=None)),
+    ("nonorm", dict(n_components=2, step=None, normalize=False, preprocessor=None)),
+    ("iter_int", dict(n_components=2, step=2, normalize=True, preprocessor=None)),
+    ("iter_float", dict(n_components=None, step=0.9, normalize=True, preprocessor=None)),
+    ("pca_pre", dict(n_components=1, step=None, normalize=True, preprocessor=PCA(n_components=4))),
+])
+def test_edr_matches_reference_edr_layer(edr_gold, name, cfg):
+    from edrgp_amd.edr import EffectiveDimensionalityReduction
+    from edrgp_amd.utils import SVDTransformer
+    X, y = edr_gold["X"], edr_gold["y"]
+    edr = EffectiveDimensionalityReduction(TanhRidgeEstimator(), SVDTransformer(), cfg["n_components"], cfg["step"],
+                                           cfg["normalize"], cfg["preprocessor"])
+    edr.fit(X, y)
+    assert close(edr.components_, edr_gold[name + "_components"])
+    assert close(np.atleast_1d(edr.subspace_variance_), edr_gold[name + "_subspace_variance"])
+    assert close(np.atleast_1d(edr.subspace_variance_ratio_), edr_gold[name + "_subspace_variance_ratio"])
+    assert close(edr.transform(X), edr_gold[name + "_transform"])
+    assert edr.num_iter == int(edr_gold[name + "_num_iter"])
+    assert close(edr.feature_importances_, edr_gold[name + "_feature_importances"])
+    assert close(edr.get_estimator_gradients(X[:10]), edr_gold[name + "_gradients"])
+
+
+def test_base_block_and_utils_match_reference(edr_gold):
+    from edrgp_amd.base import BaseEDR, BlockEDR
+    from edrgp_amd.utils import SVDTransformer, discrepancy, ort_space, subspace_variance_ratio
+    X, y = edr_gold["X"], edr_gold["y"]
+    base = BaseEDR(TanhRidgeEstimator(), SVDTransformer(), n_components=3).fit(X, y)
+    assert close(base.components_, edr_gold["base_components"])
+    assert close(base.inverse_transform(base.transform(X[:5])), edr_gold["base_inverse"])
+    base.refit(PCA(n_components=2))
+    assert close(base.refit_components_, edr_gold["base_refit_components"])
+    assert close(np.atleast_1d(base.refit_subspace_variance_ratio_), edr_gold["base_refit_ratio"])
+    blk = BlockEDR(TanhRidgeEstimator(), SVDTransformer(), n_components=[1, 2], blocks=[[0, 1, 2], [3, 4, 5]]).fit(X, y)
+    assert close(blk.components_, edr_gold["block_components"])
+    assert close(blk.transform(X), edr_gold["block_transform"])
+    svd = SVDTransformer(n_components=3).fit(edr_gold["svd_in"])
+    assert close(svd.components_, edr_gold["svd_components"])
+    assert close(svd.subspace_variance_, edr_gold["svd_variance"]) and close(svd.subspace_variance_ratio_, edr_gold["svd_ratio"])
+    sv, svr = subspace_variance_ratio(edr_gold["svd_in"], edr_gold["svr_V"])
+    assert close(sv, edr_gold["svr_variance"]) and close(svr, edr_gold["svr_ratio"])
+    sv, svr = subspace_variance_ratio(edr_gold["svd_in"], edr_gold["svr_Vn"])
+    assert close(np.atleast_1d(sv), edr_gold["svr_variance_n"]) and close(np.atleast_1d(svr), edr_gold["svr_ratio_n"])
+    assert close(discrepancy(edr_gold["disc_B"], edr_gold["svr_V"]), edr_gold["disc"])
+    assert close(ort_space(edr_gold["svr_V"]), edr_gold["ort"])
+    # float n_components: the reference raises NameError (edrgp/utils.py:148-150); here it works
+    assert SVDTransformer(n_components=0.9).fit(edr_gold["svd_in"]).components_.shape[0] >= 1

@@ -24,14 +24,19 @@ def tilde(X):
     return np.hstack([X, np.ones((X.shape[0], 1)), X * X])
 
 
-def gram_sparse_eval(kern, X, y, Z, noise):
-    N, D = X.shape
+def gram_sparse_eval(kern, X, y, Z, noise, allreduce=None):
+    """`allreduce` (sum over ranks, in place semantics by return value) marks exactly
+    the exchanges the multi-GPU path performs (api.hip: allreduce_sum calls):
+    [N, y'y], [Phi | b], and the row-dependent gradient partials."""
+    if allreduce is None:
+        allreduce = lambda a: a      # noqa: E731
+    N_local, D = X.shape
     M = Z.shape[0]
     beta = 1.0 / max(noise, 1e-8)
     K = kern.K(X, Z)
-    Phi = K.T @ K
-    b = K.T @ y
-    yy = float(y @ y)
+    N, yy = allreduce(np.array([float(N_local), float(y @ y)]))
+    stats = allreduce(np.concatenate([(K.T @ K).ravel(), K.T @ y]))
+    Phi, b = stats[:M * M].reshape(M, M), stats[M * M:]
     Kmm = kern.K(Z) + 1e-8 * np.eye(M)
     Lm = np.linalg.cholesky(Kmm)
     Li = sla.solve_triangular(Lm, np.eye(M), lower=True)
@@ -61,8 +66,10 @@ def gram_sparse_eval(kern, X, y, Z, noise):
         l = np.broadcast_to(part.lengthscale, (D,))
         T = Q * h_factor(part, X, Z)
         Tm = dKmm * h_factor(part, Z, None)
-        Gn, GmT, GmN = T.T @ Xt, Tm.T @ Zt, Tm @ Zt
-        dv = np.sum(Q * part.K(X, Z)) / part.variance + np.sum(dKmm * part.K(Z)) / part.variance - 0.5 * beta * N
+        red = allreduce(np.concatenate([(T.T @ Xt).ravel(), [np.sum(Q * part.K(X, Z)) / part.variance]]))
+        Gn, dv_nm = red[:-1].reshape(M, 2 * D + 1), red[-1]
+        GmT, GmN = Tm.T @ Zt, Tm @ Zt                       # replicated (Kmm term)
+        dv = dv_nm + np.sum(dKmm * part.K(Z)) / part.variance - 0.5 * beta * N
         dl = np.zeros(D)
         for q in range(D):
             z = Z[:, q]
