@@ -70,8 +70,11 @@ PROTOTYPES = {
                        ctypes.c_double, _c_double_p, ctypes.c_int, _c_double_p, ctypes.c_int,
                        ctypes.c_double, _c_double_p, ctypes.c_int],
     "edrgp_dbg_potrf": [_ctx_p, _c_double_p, ctypes.c_int, _c_int_p],
+    "edrgp_dbg_diag_stamps": [_ctx_p, _c_double_p, ctypes.c_int, _c_double_p],
     "edrgp_dbg_trtri": [_ctx_p, _c_double_p, _c_double_p, ctypes.c_int],
     "edrgp_dbg_syrk": [_ctx_p, _c_double_p, ctypes.c_int64, ctypes.c_int, _c_double_p],
+    "edrgp_dbg_syrk_variant": [_ctx_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                               _c_double_p, _c_double_p],
     "edrgp_dbg_kernel_matrix": [_ctx_p, _c_double_p, ctypes.c_int64, _c_double_p, ctypes.c_int64, ctypes.c_int,
                                 _c_double_p],
     "edrgp_dbg_mfma_layout": [_ctx_p, _c_double_p, _c_double_p, _c_double_p],

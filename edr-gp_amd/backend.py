@@ -191,6 +191,12 @@ class HipGP:
         check(self._lib.edrgp_dbg_syrk(self._ctx, dptr(K), K.shape[0], K.shape[1], dptr(out)))
         return out
 
+    def dbg_syrk_variant(self, N, M, variant=0, splits=0, reps=3, want_phi=False):
+        ms = ctypes.c_double(0.0)
+        phi = np.empty((M, M)) if want_phi else None
+        check(self._lib.edrgp_dbg_syrk_variant(self._ctx, N, M, variant, splits, reps, ctypes.byref(ms), dptr(phi)))
+        return ms.value, phi
+
     def dbg_kernel_matrix(self, X, X2=None):
         X = as_f64(X)
         n2 = X.shape[0] if X2 is None else X2.shape[0]

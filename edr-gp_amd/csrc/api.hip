@@ -108,6 +108,20 @@ enum {  // device scalar slots (c->scal)
     SC_COUNT = 32
 };
 
+static GemmOpts kopt(int kmode, int tri = 0, int tag = 0) {
+    GemmOpts o;
+    o.kmode = kmode;
+    o.tri = tri;
+    o.tag = tag;
+    return o;
+}
+
+// C (n x n, symmetric) = L^T L for lower-triangular L: lower tiles, zero-skipping, mirrored
+static int gram_of_lower(Ctx* c, int n, const double* L, double* C) {
+    TRY(gemm(c, true, false, n, n, n, 1.0, L, n, L, n, 0.0, C, n, kopt(K_GE_ROW | K_GE_COL, 1)));
+    return mirror_lower(c, C, n, n);
+}
+
 static KSpec make_kspec(const Ctx* c) {
     KSpec ks;
     ks.nparts = c->nparts;
@@ -247,9 +261,8 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
         const double* S = c->Knm.d();
         if (stable) {
             ProfScope ps(c, EDRGP_PROF_GRADGEMM);
-            GemmOpts o;
-            o.tag = 2;
-            TRY(gemm(c, false, true, (int)rows, M, M, 1.0, c->Knm.d(), M, Li, M, 0.0, c->W.d(), M, o));
+            TRY(gemm(c, false, true, (int)rows, M, M, 1.0, c->Knm.d(), M, Li, M, 0.0, c->W.d(), M,
+                     kopt(K_LE_COL, 0, 2)));
             TRY(gemv_t(c, (int)rows, M, 1.0, c->W.d(), M, c->y.d() + r0, btarget));
             S = c->W.d();
         }
@@ -267,8 +280,8 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
             TRY(combine3(c, M, beta, Phi, 0.0, nullptr, 0.0, nullptr, 0.0, nullptr, A));
             HIP_TRY(hipMemcpyAsync(v_v, bvec, (size_t)M * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         } else {
-            TRY(gemm(c, false, false, M, M, M, 1.0, Li, M, Phi, M, 0.0, Tm, M));
-            TRY(gemm(c, false, true, M, M, M, beta, Tm, M, Li, M, 0.0, A, M));
+            TRY(gemm(c, false, false, M, M, M, 1.0, Li, M, Phi, M, 0.0, Tm, M, kopt(K_LE_ROW)));
+            TRY(gemm(c, false, true, M, M, M, beta, Tm, M, Li, M, 0.0, A, M, kopt(K_LE_COL)));
             TRY(gemv_n(c, M, M, 1.0, Li, M, bvec, v_v));
         }
         TRY(trace_of(c, A, M, M, sc + SC_TRA));
@@ -304,9 +317,11 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
     double* Kmmi = c->mats[MAT_KMMI].d();
     {
         ProfScope ps(c, EDRGP_PROF_SMALL);
-        TRY(gemm(c, false, false, M, M, M, 1.0, LBi, M, Li, M, 0.0, R, M));
-        TRY(gemm(c, true, false, M, M, M, 1.0, R, M, R, M, 0.0, P, M));
-        TRY(gemm(c, true, false, M, M, M, 1.0, Li, M, Li, M, 0.0, Kmmi, M));
+        // R = LBi Li is lower triangular: lower tiles only, upper part stays zero
+        HIP_TRY(hipMemsetAsync(R, 0, (size_t)M * M * sizeof(double), c->stream));
+        TRY(gemm(c, false, false, M, M, M, 1.0, LBi, M, Li, M, 0.0, R, M, kopt(K_LE_ROW | K_GE_COL, 1)));
+        TRY(gram_of_lower(c, M, R, P));
+        TRY(gram_of_lower(c, M, Li, Kmmi));
     }
     if (need_post) {
         TRY(c->wv.reserve((size_t)M * sizeof(double)));
@@ -333,8 +348,8 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
         // S2 = 2 dL/dpsi2 = beta (Kmm^-1 - P - wv wv^T)
         TRY(combine3(c, M, beta, Kmmi, -beta, P, 0.0, nullptr, -beta, v_wv, S2));
         // C1 = Li^T A ; Tm = C1 Li = Lm^-T A Lm^-1
-        TRY(gemm(c, true, false, M, M, M, 1.0, Li, M, A, M, 0.0, C1, M));
-        TRY(gemm(c, false, false, M, M, M, 1.0, C1, M, Li, M, 0.0, Tm, M));
+        TRY(gemm(c, true, false, M, M, M, 1.0, Li, M, A, M, 0.0, C1, M, kopt(K_GE_ROW)));
+        TRY(gemm(c, false, false, M, M, M, 1.0, C1, M, Li, M, 0.0, Tm, M, kopt(K_GE_COL)));
         // dL/dKmm = 1/2 Kmm^-1 - 1/2 P - 1/2 wv wv^T - 1/2 Lm^-T A Lm^-1
         TRY(combine3(c, M, 0.5, Kmmi, -0.5, P, -0.5, Tm, -0.5, v_wv, dKmm));
     }
@@ -457,7 +472,7 @@ static int dense_eval(Ctx* c, bool need_grad, bool need_post, DenseOut* out) {
                           c->noise_var + 1e-8 + jit_amount(lvl, diag_mean_), nullptr, nullptr));
         TRY(potrf_lower(c, L, n, n, info));
         TRY(trtri_lower(c, L, n, Li, n, n));
-        TRY(gemm(c, true, false, n, n, n, 1.0, Li, n, Li, n, 0.0, Kyi, n));
+        TRY(gram_of_lower(c, n, Li, Kyi));
         TRY(gemv_n(c, n, n, 1.0, Kyi, n, c->y.d(), alpha));
         TRY(sum_log_diag(c, L, n, n, sc + SC_SUMLOGL));
         TRY(dot(c, c->y.d(), alpha, n, sc + SC_YALPHA));
@@ -874,6 +889,23 @@ int edrgp_dbg_potrf(edrgp_ctx* ctx, double* A, int n, int* info) {
     return s;
 }
 
+// diagnostic: phase stamps (shader cycles) of one diagonal-block kernel launch
+int edrgp_dbg_diag_stamps(edrgp_ctx* ctx, const double* A64x64, int do_chol, double* stamps6) {
+    CTX(ctx);
+    DBuf dA, dD, dS;
+    TRY(dA.reserve(64 * 64 * sizeof(double)));
+    TRY(dD.reserve(64 * 64 * sizeof(double)));
+    TRY(dS.reserve(8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemcpy(dA.d(), A64x64, 64 * 64 * sizeof(double), hipMemcpyHostToDevice));
+    int s = diag_block_stamps(c, dA.d(), dD.d(), static_cast<unsigned long long*>(dS.p), do_chol);
+    if (s == EDRGP_OK && hipStreamSynchronize(c->stream) != hipSuccess) s = EDRGP_ERR_HIP;
+    unsigned long long h[8] = {0};
+    if (s == EDRGP_OK) HIP_TRY(hipMemcpy(h, dS.p, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 6; ++i) stamps6[i] = (double)(h[i] - h[0]);
+    dA.release(); dD.release(); dS.release();
+    return s;
+}
+
 int edrgp_dbg_trtri(edrgp_ctx* ctx, const double* L, double* Linv, int n) {
     CTX(ctx);
     DBuf dL, dI;
@@ -898,6 +930,43 @@ int edrgp_dbg_syrk(edrgp_ctx* ctx, const double* K, int64_t N, int M, double* Ph
     c->drain_events();
     if (s == EDRGP_OK) HIP_TRY(hipMemcpy(Phi, dP.d(), (size_t)M * M * sizeof(double), hipMemcpyDeviceToHost));
     dK.release(); dP.release();
+    return s;
+}
+
+// Times `reps` launches of a Phi = K^T K kernel variant on a device-generated K
+// (uniform [0,1) pattern); variant 0 = production path.  Phi_out (M x M) optional.
+int edrgp_dbg_syrk_variant(edrgp_ctx* ctx, int64_t N, int M, int variant, int splits, int reps, double* avg_ms,
+                           double* Phi_out) {
+    CTX(ctx);
+    if (N <= 0 || N % 16 || M % 128 || reps < 1) { set_error("dbg_syrk_variant: need N %% 16 == 0, M %% 128 == 0"); return EDRGP_ERR_INVALID; }
+    TRY(c->Knm.reserve((size_t)N * M * sizeof(double)));
+    TRY(c->mats[MAT_PHI].reserve(((size_t)M * M + M + 8) * sizeof(double)));
+    TRY(fill_pattern(c, c->Knm.d(), (size_t)N * M, 12345ULL));
+    double* Phi = c->mats[MAT_PHI].d();
+    const int saved = c->syrk_splits;
+    c->syrk_splits = splits;
+    auto run = [&]() -> int {
+        if (variant == 0) return syrk_tn(c, c->Knm.d(), N, M, M, Phi, M, false);
+        return syrk_variant(c, c->Knm.d(), (int)N, M, M, variant, splits, Phi);
+    };
+    int s = run();
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (s == EDRGP_OK) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, c->stream));
+        for (int r = 0; r < reps && s == EDRGP_OK; ++r) s = run();
+        HIP_TRY(hipEventRecord(e1, c->stream));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        if (avg_ms) *avg_ms = ms / reps;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    c->syrk_splits = saved;
+    c->drain_events();
+    if (s == EDRGP_OK && Phi_out) HIP_TRY(hipMemcpy(Phi_out, Phi, (size_t)M * M * sizeof(double), hipMemcpyDeviceToHost));
     return s;
 }
 

@@ -71,8 +71,16 @@ struct GemmOpts {
     int limM_base = 0, limM_stride = 0;      // M_eff(z) = min(M, limM_base - z*limM_stride)
     int limK_base = 0, limK_stride = 0;      // K_eff(z) likewise
     int tri = 0;                             // 1: only tiles with ti >= tj (M == N)
+    int kmode = 0;                           // zero-skipping for triangular operands, see K_* below
     int force_tile = 0;                      // 64 or 128; 0 = heuristic
 };
+
+// k-range restrictions (GemmOpts::kmode) for triangular operands
+constexpr int K_LE_ROW = 1;   // op(A)[i][k] == 0 for k > i   (A lower triangular, not transposed)
+constexpr int K_GE_ROW = 2;   // op(A)[i][k] == 0 for k < i   (A = L^T)
+constexpr int K_LE_COL = 4;   // op(B)[k][j] == 0 for k > j   (B = L^T)
+constexpr int K_GE_COL = 8;   // op(B)[k][j] == 0 for k < j   (B lower triangular, not transposed)
+int mirror_lower(Ctx* c, double* A, int n, int lda);          // copy the lower triangle onto the upper
 
 // C = alpha * op(A) op(B) + beta * C, row-major fp64, MFMA f64 16x16x4.
 int gemm(Ctx* c, bool transA, bool transB, int M, int N, int K, double alpha,
@@ -85,6 +93,11 @@ int gemm(Ctx* c, bool transA, bool transB, int M, int N, int K, double alpha,
 int syrk_tn(Ctx* c, const double* K, int64_t rows, int M, int ldk, double* Phi, int ldphi,
             bool accumulate);
 
+int slab_reduce_mirror(Ctx* c, const double* slabs, int splits, long long slabStride, int M, double* Phi);
+// experimental variants (exp_syrk.hip)
+int syrk_variant(Ctx* c, const double* K, int rows, int M, int ld, int variant, int splits, double* Phi);
+int fill_pattern(Ctx* c, double* K, size_t n, unsigned long long seed);
+
 // ------------------------------------------------------- Cholesky / triangular
 // In-place lower Cholesky of the n x n matrix A (row-major, lda); the strict
 // upper triangle is zeroed.  *info_dev (device int) receives 0 or the 1-based
@@ -92,6 +105,7 @@ int syrk_tn(Ctx* c, const double* K, int64_t rows, int M, int ldk, double* Phi, 
 int potrf_lower(Ctx* c, double* A, int n, int lda, int* info_dev);
 // Linv = L^-1 for lower-triangular L (explicit zeros above the diagonal of the output).
 int trtri_lower(Ctx* c, const double* L, int ldl, double* Linv, int ldi, int n);
+int diag_block_stamps(Ctx* c, double* A64, double* Dinv64, unsigned long long* stamps_dev, int do_chol);
 
 // -------------------------------------------------------------- vector helpers
 int gemv_n(Ctx* c, int M, int N, double alpha, const double* A, int lda, const double* x, double* y);

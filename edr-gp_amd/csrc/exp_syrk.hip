@@ -1,0 +1,123 @@
+// Experimental Phi = K^T K kernels for A/B measurements against the production
+// LDS-staged kernel (la_gemm.hip).  Reached only through edrgp_dbg_syrk_variant.
+// Aligned shapes only: M % 128 == 0, rows % 16 == 0, ld even.
+#include "common.h"
+
+namespace edrgp {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__global__ void fill_pattern_kernel(double* __restrict__ K, size_t n, unsigned long long seed) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        unsigned long long x = (i + 1) * 0x9E3779B97F4A7C15ULL + seed;
+        x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 32;
+        K[i] = (double)(x >> 11) * (1.0 / 9007199254740992.0);        // uniform [0, 1) like kernel values
+    }
+}
+
+__device__ __forceinline__ void tri_tile(int t, int& ti, int& tj) {
+    ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((long long)(ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while ((long long)ti * (ti + 1) / 2 > t) --ti;
+    tj = t - (int)((long long)ti * (ti + 1) / 2);
+}
+
+__device__ __forceinline__ int xcd_remap(int bid, int nt) {
+    const int q = nt >> 3, r = nt & 7, x = bid & 7, in = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + in;
+}
+
+// ---- variant 1: no LDS, no barriers.  Every wave streams its own MFMA fragments
+// straight from global memory (L1/L2) with a two-stage register ring.
+template <int KS>   // k-steps (of 4 rows) per stage
+__global__ __launch_bounds__(256, 2) void syrk_direct_kernel(const double* __restrict__ K, int rows, int M, int ld,
+                                                             double* __restrict__ slabs, long long slabStride,
+                                                             int splits) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, lq = lane >> 4;
+    int ti, tj;
+    tri_tile(xcd_remap(blockIdx.x, gridDim.x), ti, tj);
+    const int kt_total = rows / 4;                       // k-steps
+    const int per = ((kt_total + splits - 1) / splits + KS - 1) / KS * KS;
+    const int ks0 = blockIdx.y * per;
+    const int ks1 = min(kt_total, ks0 + per);
+    const double* pa = K + (size_t)(ti * 128 + wm * 64 + lr);
+    const double* pb = K + (size_t)(tj * 128 + wn * 64 + lr);
+
+    d4 acc[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] = d4{0.0, 0.0, 0.0, 0.0};
+
+    double a0[KS][4], b0[KS][4], a1[KS][4], b1[KS][4];
+    auto load = [&](double (&a)[KS][4], double (&b)[KS][4], int ks) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int k = (ks + s) * 4 + lq;
+            const bool ok = (ks + s) < ks1;
+            const size_t off = (size_t)(ok ? k : 0) * ld;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                a[s][x] = ok ? pa[off + x * 16] : 0.0;
+                b[s][x] = ok ? pb[off + x * 16] : 0.0;
+            }
+        }
+    };
+    auto compute = [&](const double (&a)[KS][4], const double (&b)[KS][4]) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y)
+                    acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][x], b[s][y], acc[x][y], 0, 0, 0);
+    };
+    if (ks0 < ks1) {
+        load(a0, b0, ks0);
+        for (int ks = ks0; ks < ks1; ks += 2 * KS) {
+            load(a1, b1, ks + KS);
+            compute(a0, b0);
+            load(a0, b0, ks + 2 * KS);
+            compute(a1, b1);
+        }
+    }
+    double* C = slabs + (long long)blockIdx.y * slabStride;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            const int col = tj * 128 + wn * 64 + y * 16 + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = ti * 128 + wm * 64 + x * 16 + lq + 4 * r;
+                C[(size_t)row * M + col] = acc[x][y][r];
+            }
+        }
+}
+
+int syrk_variant(Ctx* c, const double* K, int rows, int M, int ld, int variant, int splits, double* Phi) {
+    const int tm = M / 128;
+    const long long nt = (long long)tm * (tm + 1) / 2;
+    if (splits <= 0) splits = (int)std::max<long long>(1, (8LL * c->num_cu) / nt);
+    const long long slabStride = (long long)M * M;
+    TRY(c->slabs.reserve((size_t)splits * slabStride * sizeof(double)));
+    dim3 grid((unsigned)nt, (unsigned)splits);
+    if (variant == 1) hipLaunchKernelGGL((syrk_direct_kernel<2>), grid, dim3(256), 0, c->stream, K, rows, M, ld, c->slabs.d(), slabStride, splits);
+    else if (variant == 2) hipLaunchKernelGGL((syrk_direct_kernel<1>), grid, dim3(256), 0, c->stream, K, rows, M, ld, c->slabs.d(), slabStride, splits);
+    else { set_error("unknown syrk variant %d", variant); return EDRGP_ERR_INVALID; }
+    HIP_TRY(hipGetLastError());
+    if (Phi) TRY(slab_reduce_mirror(c, c->slabs.d(), splits, slabStride, M, Phi));
+    return EDRGP_OK;
+}
+
+int fill_pattern(Ctx* c, double* K, size_t n, unsigned long long seed) {
+    hipLaunchKernelGGL(fill_pattern_kernel, dim3(2048), dim3(256), 0, c->stream, K, n, seed);
+    HIP_TRY(hipGetLastError());
+    return EDRGP_OK;
+}
+
+}  // namespace edrgp

@@ -38,6 +38,8 @@ struct GemmArgs {
     long long slabStride;
     int tiles_m, tiles_n, tri;
     int vecA, vecB;
+    int kmode;          // triangular operands: bit0 k <= row tile end, bit1 k >= row tile start,
+                        //                      bit2 k <= col tile end, bit3 k >= col tile start
 };
 
 // Stage loader.  KM = true : source element (k, i) at P[k*ld + i]
@@ -150,8 +152,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     // ---- split-K range (in units of BK)
     const int kt_total = (Keff + BK - 1) / BK;
     const int kt_per = (kt_total + g.splits - 1) / g.splits;
-    const int kt0 = blockIdx.y * kt_per;
-    const int kt1 = min(kt_total, kt0 + kt_per);
+    int kt0 = blockIdx.y * kt_per;
+    int kt1 = min(kt_total, kt0 + kt_per);
+    if (g.kmode) {          // skip k-tiles where a triangular operand is identically zero
+        int k_lo = 0, k_hi = Keff;
+        if (g.kmode & 1) k_hi = min(k_hi, m0 + BM);
+        if (g.kmode & 2) k_lo = max(k_lo, m0);
+        if (g.kmode & 4) k_hi = min(k_hi, n0 + BN);
+        if (g.kmode & 8) k_lo = max(k_lo, n0);
+        kt0 = max(kt0, k_lo / BK);
+        kt1 = min(kt1, (k_hi + BK - 1) / BK);
+    }
 
     d4 acc[TM][TN];
 #pragma unroll
@@ -266,6 +277,7 @@ static int gemm_impl(Ctx* c, bool transA, bool transB, int M, int N, int K, doub
     g.limK_base = o.limK_base; g.limK_stride = o.limK_stride;
     g.splits = splits;
     g.tri = o.tri;
+    g.kmode = o.kmode;
     g.tiles_m = (M + tile - 1) / tile;
     g.tiles_n = (N + tile - 1) / tile;
     g.vecA = aligned16(A) && (lda % 2 == 0) && (o.strideA % 2 == 0);
@@ -314,6 +326,27 @@ int gemm(Ctx* c, bool transA, bool transB, int M, int N, int K, double alpha, co
         return EDRGP_OK;
     }
     return gemm_impl(c, transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, o, 1, nullptr, 0, 0);
+}
+
+__global__ void mirror_lower_kernel(double* __restrict__ A, int n, int lda) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i < n && j < i) A[(size_t)j * lda + i] = A[(size_t)i * lda + j];
+}
+
+int mirror_lower(Ctx* c, double* A, int n, int lda) {
+    dim3 blk(64, 4), grd((n + 63) / 64, (n + 3) / 4);
+    hipLaunchKernelGGL(mirror_lower_kernel, grd, blk, 0, c->stream, A, n, lda);
+    HIP_TRY(hipGetLastError());
+    return EDRGP_OK;
+}
+
+int slab_reduce_mirror(Ctx* c, const double* slabs, int splits, long long slabStride, int M, double* Phi) {
+    dim3 blk(64, 4), grd((M + 63) / 64, (M + 3) / 4);
+    hipLaunchKernelGGL(slab_reduce_kernel, grd, blk, 0, c->stream, slabs, splits, slabStride, M, M, M, 1.0, 0.0, Phi,
+                       M, 1);
+    HIP_TRY(hipGetLastError());
+    return EDRGP_OK;
 }
 
 int syrk_tn(Ctx* c, const double* K, int64_t rows, int M, int ldk, double* Phi, int ldphi, bool accumulate) {

@@ -144,8 +144,12 @@ int  edrgp_dbg_gemm(edrgp_ctx* ctx, int transA, int transB, int M, int N, int K,
                     double alpha, const double* A, int lda, const double* B, int ldb,
                     double beta, double* C, int ldc);
 int  edrgp_dbg_potrf(edrgp_ctx* ctx, double* A, int n, int* info);
+int  edrgp_dbg_diag_stamps(edrgp_ctx* ctx, const double* A64x64, int do_chol, double* stamps6);
 int  edrgp_dbg_trtri(edrgp_ctx* ctx, const double* L, double* Linv, int n);
 int  edrgp_dbg_syrk(edrgp_ctx* ctx, const double* K, int64_t N, int M, double* Phi);
+/* times a Phi = K^T K kernel variant on a device-generated K (0 = production kernel) */
+int  edrgp_dbg_syrk_variant(edrgp_ctx* ctx, int64_t N, int M, int variant, int splits, int reps,
+                            double* avg_ms, double* Phi_out);
 int  edrgp_dbg_kernel_matrix(edrgp_ctx* ctx, const double* X, int64_t N,
                              const double* X2, int64_t N2, int D, double* K);
 int  edrgp_dbg_mfma_layout(edrgp_ctx* ctx, const double* A16x4, const double* B4x16, double* C16x16);
