@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstring>
 #include <algorithm>
+#include <chrono>
 
 namespace edrgp {
 
@@ -108,6 +109,39 @@ enum {  // device scalar slots (c->scal)
     SC_COUNT = 32
 };
 
+// Runs the enclosed launches on the context's side stream (with its own scratch
+// buffers); join_into_main() makes the main stream wait for them.
+struct SideStream {
+    Ctx* c;
+    explicit SideStream(Ctx* c_) : c(c_) { swap(); }
+    ~SideStream() { swap(); }
+    void swap() {
+        std::swap(c->stream, c->stream2);
+        std::swap(c->red, c->red2);
+        std::swap(c->slabs, c->slabs2);
+    }
+    // while active c->stream IS the side stream and c->stream2 the main one
+    int start_after_main() {
+        HIP_TRY(hipEventRecord(c->ev_fork, c->stream2));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_fork, 0));
+        return EDRGP_OK;
+    }
+    int mark_done() {                      // side work queued so far is what the main stream will wait for
+        HIP_TRY(hipEventRecord(c->ev_join, c->stream));
+        return EDRGP_OK;
+    }
+    int join_into_main() {
+        TRY(mark_done());
+        HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_join, 0));
+        return EDRGP_OK;
+    }
+};
+
+static int main_waits_side(Ctx* c) {       // outside a SideStream scope: c->stream is the main stream
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    return EDRGP_OK;
+}
+
 static GemmOpts kopt(int kmode, int tri = 0, int tag = 0) {
     GemmOpts o;
     o.kmode = kmode;
@@ -186,7 +220,22 @@ struct SparseOut {
 // One evaluation of the Titsias bound (VarDTC.inference) with optional
 // gradients / posterior.  Returns EDRGP_ERR_NOT_PD when a factorisation fails
 // at every jitter level.
+struct HostTrace {          // option "trace": host wall-clock of the phases of one evaluation, to stderr
+    bool on;
+    std::chrono::steady_clock::time_point t0, last;
+    explicit HostTrace(bool on_) : on(on_) { t0 = last = std::chrono::steady_clock::now(); }
+    void mark(const char* what) {
+        if (!on) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[edrgp trace] %-28s +%8.3f ms (total %8.3f)\n", what,
+                std::chrono::duration<double, std::milli>(now - last).count(),
+                std::chrono::duration<double, std::milli>(now - t0).count());
+        last = now;
+    }
+};
+
 static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
+    HostTrace tr(c->trace);
     if (!c->have_data || !c->have_Z || !c->have_kernel) {
         set_error("sparse evaluation needs set_data, set_inducing and set_kernel first");
         return EDRGP_ERR_STATE;
@@ -225,52 +274,79 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
 
     // ---- phase 1: Kmm + (1e-8 + jitter) I, Lm (jitchol ladder), Lm^-1
     const double kmm_diag_mean = var_sum(c) + 1e-8;
-    for (int lvl = -1;;) {
-        ProfScope ps(c, EDRGP_PROF_SMALL);
-        TRY(kernel_matrix(c, ks, c->Z.d(), M, c->Z.d(), M, Lm, M, 1, 1e-8 + jit_amount(lvl, kmm_diag_mean),
-                          nullptr, nullptr));
-        TRY(potrf_lower(c, Lm, M, M, info + 0));
-        TRY(diag_minmax(c, Lm, M, M, sc + SC_DIAGMIN));
-        HIP_TRY(hipMemcpyAsync(h_sc, sc, sizeof(h_sc), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(h_info, info, sizeof(h_info), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        if (h_info[0] == 0) break;
-        if (++lvl > 4) { set_error("Kmm not positive definite, even with jitter"); return EDRGP_ERR_NOT_PD; }
-    }
-    TRY(trtri_lower(c, Lm, M, Li, M, M));
-    // Pivot-ratio proxy of cond(Kmm).  The Gram form A = beta Li (K^T K) Li^T loses
-    // accuracy ~ eps * cond(Kmm); beyond the threshold switch to the GPy-ordered
-    // form A = beta (K Li^T)^T (K Li^T), whose error grows with sqrt(cond) only.
-    const double pr = h_sc[SC_DIAGMAX] / h_sc[SC_DIAGMIN];
-    const bool stable = (c->stats_mode == 2) || (c->stats_mode == 0 && pr * pr > c->pivot_ratio_max);
-    c->last_mode = stable ? 2 : 1;
+    auto phase1 = [&]() -> int {
+        for (int lvl = -1;;) {
+            ProfScope ps(c, EDRGP_PROF_SMALL);
+            TRY(kernel_matrix(c, ks, c->Z.d(), M, c->Z.d(), M, Lm, M, 1, 1e-8 + jit_amount(lvl, kmm_diag_mean),
+                              nullptr, nullptr));
+            TRY(potrf_lower(c, Lm, M, M, info + 0));
+            TRY(diag_minmax(c, Lm, M, M, sc + SC_DIAGMIN));
+            HIP_TRY(hipMemcpyAsync(h_sc, sc, sizeof(h_sc), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(h_info, info, sizeof(h_info), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (h_info[0] == 0) break;
+            if (++lvl > 4) { set_error("Kmm not positive definite, even with jitter"); return EDRGP_ERR_NOT_PD; }
+        }
+        TRY(trtri_lower(c, Lm, M, Li, M, M));
+        return EDRGP_OK;
+    };
 
     // ---- phase 2: row statistics.  gram: Phi = K^T K, b = K^T y.
     //      stable: Phi := (K Li^T)^T (K Li^T), b := (K Li^T)^T y  (= Li b)
     bool k_resident = false;
-    if (stable) TRY(c->W.reserve((size_t)chunk * M * sizeof(double)));
-    for (int64_t ch = 0; ch < nchunks; ++ch) {
-        const int64_t r0 = ch * chunk;
-        const int64_t rows = std::min<int64_t>(chunk, N - r0);
-        double* btarget = (ch == 0) ? bvec : v_tmp;
+    auto phase2 = [&](bool stable) -> int {
+        if (stable) TRY(c->W.reserve((size_t)chunk * M * sizeof(double)));
+        for (int64_t ch = 0; ch < nchunks; ++ch) {
+            const int64_t r0 = ch * chunk;
+            const int64_t rows = std::min<int64_t>(chunk, N - r0);
+            double* btarget = (ch == 0) ? bvec : v_tmp;
+            {
+                ProfScope ps(c, EDRGP_PROF_KBUILD);
+                TRY(kernel_matrix(c, ks, c->X.d() + (size_t)r0 * D, rows, c->Z.d(), M, c->Knm.d(), M, 0, 0.0,
+                                  stable ? nullptr : c->y.d() + r0, stable ? nullptr : btarget));
+            }
+            const double* S = c->Knm.d();
+            if (stable) {
+                ProfScope ps(c, EDRGP_PROF_GRADGEMM);
+                TRY(gemm(c, false, true, (int)rows, M, M, 1.0, c->Knm.d(), M, Li, M, 0.0, c->W.d(), M,
+                         kopt(K_LE_COL, 0, 2)));
+                TRY(gemv_t(c, (int)rows, M, 1.0, c->W.d(), M, c->y.d() + r0, btarget));
+                S = c->W.d();
+            }
+            if (ch > 0) TRY(vec_axpy(c, M, 1.0, v_tmp, bvec));
+            TRY(syrk_tn(c, S, rows, M, M, Phi, M, ch > 0));
+        }
+        k_resident = (nchunks == 1);
+        if (c->comm) TRY(allreduce_sum(c, Phi, (size_t)M * M + M));
+        return EDRGP_OK;
+    };
+
+    // The O(M^3), latency-bound phase 1 does not depend on the rows: when the
+    // Gram form is expected (it ran last time, or is forced) the row pass is
+    // queued first on the main stream and phase 1 runs beside it on the side
+    // stream.  The pivot-ratio proxy of cond(Kmm) is known only after phase 1;
+    // if it then asks for the stable form, the row pass is redone that way.
+    // (Gram form: A = beta Li (K^T K) Li^T, rounding error ~ eps cond(Kmm);
+    //  stable form: A = beta (K Li^T)^T (K Li^T), error ~ eps sqrt(cond).)
+    tr.mark("setup");
+    const bool optimistic = c->overlap && (c->stats_mode == 1 || (c->stats_mode == 0 && c->last_mode != 2));
+    if (optimistic) {
+        TRY(phase2(false));
         {
-            ProfScope ps(c, EDRGP_PROF_KBUILD);
-            TRY(kernel_matrix(c, ks, c->X.d() + (size_t)r0 * D, rows, c->Z.d(), M, c->Knm.d(), M, 0, 0.0,
-                              stable ? nullptr : c->y.d() + r0, stable ? nullptr : btarget));
+            SideStream side(c);
+            int st = phase1();
+            if (st == EDRGP_OK) st = side.join_into_main();
+            if (st != EDRGP_OK) return st;
         }
-        const double* S = c->Knm.d();
-        if (stable) {
-            ProfScope ps(c, EDRGP_PROF_GRADGEMM);
-            TRY(gemm(c, false, true, (int)rows, M, M, 1.0, c->Knm.d(), M, Li, M, 0.0, c->W.d(), M,
-                     kopt(K_LE_COL, 0, 2)));
-            TRY(gemv_t(c, (int)rows, M, 1.0, c->W.d(), M, c->y.d() + r0, btarget));
-            S = c->W.d();
-        }
-        if (ch > 0) TRY(vec_axpy(c, M, 1.0, v_tmp, bvec));
-        TRY(syrk_tn(c, S, rows, M, M, Phi, M, ch > 0));
+    } else {
+        TRY(phase1());
     }
-    k_resident = (nchunks == 1);
-    if (c->comm) TRY(allreduce_sum(c, Phi, (size_t)M * M + M));
+    const double pr = h_sc[SC_DIAGMAX] / h_sc[SC_DIAGMIN];
+    const bool stable = (c->stats_mode == 2) || (c->stats_mode == 0 && pr * pr > c->pivot_ratio_max);
+    c->last_mode = stable ? 2 : 1;
+    tr.mark("phase1 (+queued phase2)");
+    if (!optimistic || stable) TRY(phase2(stable));
+    tr.mark("phase2 queued");
 
     // ---- phase 3: A, B = I + A (jitchol ladder), LB^-1, the M-vectors and scalars
     for (int lvl = -1;;) {
@@ -305,6 +381,7 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
         if (++lvl > 4) { set_error("I + A not positive definite, even with jitter"); return EDRGP_ERR_NOT_PD; }
     }
     c->drain_events();
+    tr.mark("phase3 synced");
 
     const double psi0sum = gl.N * var_sum(c);
     const double trA = h_sc[SC_TRA], data_fit = h_sc[SC_DATAFIT];
@@ -347,16 +424,38 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
         ProfScope ps(c, EDRGP_PROF_SMALL);
         // S2 = 2 dL/dpsi2 = beta (Kmm^-1 - P - wv wv^T)
         TRY(combine3(c, M, beta, Kmmi, -beta, P, 0.0, nullptr, -beta, v_wv, S2));
+    }
+    TRY(c->gt_mm.reserve((size_t)2 * np * M * Wd * sizeof(double)));
+    // Kmm term (X2 = None upstream): dL/dKmm, its element-wise factor, then T^T Zt and
+    // T Zt.  O(M^3) and independent of the rows: runs on the side stream beside the
+    // N x M x M gradient contraction.
+    auto kmm_term = [&]() -> int {
+        ProfScope ps(c, EDRGP_PROF_SMALL);
         // C1 = Li^T A ; Tm = C1 Li = Lm^-T A Lm^-1
         TRY(gemm(c, true, false, M, M, M, 1.0, Li, M, A, M, 0.0, C1, M, kopt(K_GE_ROW)));
         TRY(gemm(c, false, false, M, M, M, 1.0, C1, M, Li, M, 0.0, Tm, M, kopt(K_GE_COL)));
         // dL/dKmm = 1/2 Kmm^-1 - 1/2 P - 1/2 wv wv^T - 1/2 Lm^-T A Lm^-1
         TRY(combine3(c, M, 0.5, Kmmi, -0.5, P, -0.5, Tm, -0.5, v_wv, dKmm));
+        for (int p = 0; p < np; ++p) {
+            TRY(grad_elementwise(c, ks, p, c->Z.d(), nullptr, M, c->Z.d(), M, dKmm, M, 0.0, nullptr, Tmm, M,
+                                 sc + SC_DVAR_MM + p));
+            TRY(gemm(c, true, false, M, Wd, M, 1.0, Tmm, M, c->Zt.d(), Wd, 0.0,
+                     c->gt_mm.d() + (size_t)(2 * p) * M * Wd, Wd));
+            TRY(gemm(c, false, false, M, Wd, M, 1.0, Tmm, M, c->Zt.d(), Wd, 0.0,
+                     c->gt_mm.d() + (size_t)(2 * p + 1) * M * Wd, Wd));
+        }
+        return EDRGP_OK;
+    };
+    if (c->overlap) {
+        SideStream side(c);
+        int st = side.start_after_main();
+        if (st == EDRGP_OK) st = kmm_term();
+        if (st == EDRGP_OK) st = side.mark_done();
+        if (st != EDRGP_OK) return st;
     }
     TRY(c->W.reserve((size_t)chunk * M * sizeof(double)));
     TRY(c->T.reserve((size_t)chunk * M * sizeof(double)));
     TRY(c->gt_nm.reserve((size_t)np * M * Wd * sizeof(double)));
-    TRY(c->gt_mm.reserve((size_t)2 * np * M * Wd * sizeof(double)));
     for (int64_t ch = 0; ch < nchunks; ++ch) {
         const int64_t r0 = ch * chunk;
         const int64_t rows = std::min<int64_t>(chunk, N - r0);
@@ -378,15 +477,9 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
                      ch > 0 ? 1.0 : 0.0, c->gt_nm.d() + (size_t)p * M * Wd, Wd));
         }
     }
-    // Kmm term (X2 = None upstream): element-wise factor of dL/dKmm, then T^T Zt and T Zt
-    for (int p = 0; p < np; ++p) {
-        TRY(grad_elementwise(c, ks, p, c->Z.d(), nullptr, M, c->Z.d(), M, dKmm, M, 0.0, nullptr, Tmm, M,
-                             sc + SC_DVAR_MM + p));
-        TRY(gemm(c, true, false, M, Wd, M, 1.0, Tmm, M, c->Zt.d(), Wd, 0.0,
-                 c->gt_mm.d() + (size_t)(2 * p) * M * Wd, Wd));
-        TRY(gemm(c, false, false, M, Wd, M, 1.0, Tmm, M, c->Zt.d(), Wd, 0.0,
-                 c->gt_mm.d() + (size_t)(2 * p + 1) * M * Wd, Wd));
-    }
+    tr.mark("grad queued");
+    if (c->overlap) TRY(main_waits_side(c));
+    else TRY(kmm_term());
     if (c->comm) {
         TRY(allreduce_sum(c, c->gt_nm.d(), (size_t)np * M * Wd));
         TRY(allreduce_sum(c, sc + SC_DVAR_NM, EDRGP_MAX_PARTS));
@@ -396,8 +489,10 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
     HIP_TRY(hipMemcpyAsync(g_nm.data(), c->gt_nm.d(), g_nm.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(g_mm.data(), c->gt_mm.d(), g_mm.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(Zh.data(), c->Z.d(), Zh.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    tr.mark("grad D2H queued");
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->drain_events();
+    tr.mark("grad synced");
 
     // ---- finishing on the host: O(M D) arithmetic
     out->dvar.assign(np, 0.0);
@@ -433,6 +528,7 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
         dR += beta * (0.5 * sumA_DBi - data_fit);
         out->dnoise = dR;
     }
+    tr.mark("host finishing");
     return EDRGP_OK;
 }
 
@@ -604,6 +700,15 @@ int edrgp_ctx_create(int device, edrgp_ctx** ctx) {
     c->device = device;
     c->num_cu = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    {
+        // side stream at the highest priority: its short, latency-bound kernels should
+        // take the next free workgroup slot ahead of the row pass' queue
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     *ctx = reinterpret_cast<edrgp_ctx*>(c);
     return EDRGP_OK;
 }
@@ -613,6 +718,7 @@ int edrgp_ctx_destroy(edrgp_ctx* ctx) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream2);
     c->drain_events();
     if (c->comm) edrgp_comm_destroy(ctx);
     DBuf* bufs[] = {&c->X, &c->y, &c->Z, &c->Xt, &c->Zt, &c->invl, &c->wv, &c->winv, &c->Knm, &c->W, &c->T, &c->slabs,
@@ -620,6 +726,11 @@ int edrgp_ctx_destroy(edrgp_ctx* ctx) {
     for (DBuf* b : bufs) b->release();
     for (auto& m : c->mats) m.release();
     for (auto& v : c->tmpvec) v.release();
+    c->red2.release();
+    c->slabs2.release();
+    (void)hipEventDestroy(c->ev_fork);
+    (void)hipEventDestroy(c->ev_join);
+    (void)hipStreamDestroy(c->stream2);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return EDRGP_OK;
@@ -632,6 +743,7 @@ int edrgp_ctx_destroy(edrgp_ctx* ctx) {
 
 int edrgp_sync(edrgp_ctx* ctx) {
     CTX(ctx);
+    HIP_TRY(hipStreamSynchronize(c->stream2));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->drain_events();
     return EDRGP_OK;
@@ -645,6 +757,8 @@ int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
     else if (!std::strcmp(key, "profile")) c->profile = (value != 0.0);
     else if (!std::strcmp(key, "stats_mode")) c->stats_mode = (int)value;          // 0 auto, 1 gram, 2 stable
     else if (!std::strcmp(key, "pivot_ratio_max")) c->pivot_ratio_max = value;
+    else if (!std::strcmp(key, "overlap")) c->overlap = (value != 0.0);
+    else if (!std::strcmp(key, "trace")) c->trace = (value != 0.0);
     else { set_error("unknown option %s", key); return EDRGP_ERR_INVALID; }
     return EDRGP_OK;
 }

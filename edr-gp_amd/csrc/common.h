@@ -150,6 +150,11 @@ int mfma_layout_probe(Ctx* c, const double* A, const double* B, double* C);  // 
 struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;        // side stream: latency-bound O(M^3) work beside the row pass
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    DBuf red2, slabs2;                    // scratch used while launching on the side stream
+    bool overlap = true;
+    bool trace = false;
     int num_cu = 256;
 
     // data

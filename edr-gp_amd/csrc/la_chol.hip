@@ -1,20 +1,32 @@
 // Blocked right-looking Cholesky and recursive triangular inverse, fp64.
 //
-// potrf_lower: nb = 64.  Per step: (1) one single-wave workgroup factors the
-// 64x64 diagonal block in LDS (left-looking column Cholesky, one lane per row)
-// and inverts it; (2) panel  L21 = A21 * inv(L11)^T  as an MFMA GEMM;
-// (3) trailing update  A22 -= L21 L21^T  on the lower tile set (MFMA GEMM).
-// GPy reaches this through jitchol -> LAPACK dpotrf (GPy/util/linalg.py).
+// potrf_lower: nb = 64.  Per step: (1) ONE single-wave workgroup factors the
+// 64x64 diagonal block (rows in registers, right-looking, fully unrolled) and
+// inverts it with fp64 MFMA (below); (2) panel  L21 = A21 inv(L11)^T  as an MFMA
+// GEMM, in place; (3) trailing update  A22 -= L21 L21^T  on the lower 64x64 tile
+// set (MFMA GEMM).  GPy reaches this through jitchol -> LAPACK dpotrf.
 //
 // trtri_lower: Linv = L^-1 by recursive doubling: the 64x64 diagonal blocks are
-// inverted in one batched launch, then at level s every pair of adjacent
-// s-blocks is merged with two batched MFMA GEMMs
+// inverted in one batched launch of the same kernel, then at level s every pair
+// of adjacent s-blocks is merged with two batched MFMA GEMMs
 //     inv([[L11, 0], [L21, L22]]) = [[I11, 0], [-I22 L21 I11, I22]].
+//
+// 64x64 inverse on one wave.  A lone wave gets a fraction of the LDS rate
+// (measured: 61k cycles for the 2016 broadcast reads of a scalar substitution;
+// v_readlane broadcasts 2x slower still; scalar-cache loads latency-bound), so
+// the bulk goes through the matrix pipe: the four 16x16 diagonal blocks are
+// inverted by a 16-step substitution (lane 16b+c owns column c of block b), the
+// six off-diagonal 16x16 blocks by block substitution
+//     X_ij = -T_ii sum_{k=j}^{i-1} L_ik X_kj
+// as v_mfma_f64_16x16x4_f64 products.  An accumulator tile IS a B operand for
+// the next product (C/D reg r holds row (lane>>4)+4r = k of k-step r), so the X
+// tiles never leave registers; only A fragments (blocks of L and T) come from LDS.
 #include "common.h"
 
 namespace edrgp {
 
 constexpr int NB = 64;
+typedef double d4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -23,33 +35,10 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
-// sqrt(p) and 1/sqrt(p) by Goldschmidt iteration from v_rsq_f64 (p > 0, normal
-// range): two coupled refinements + one residual correction, ~1 ulp.
-__device__ __forceinline__ void sqrt_rsqrt(double p, double& sq, double& rs) {
-    const double y = __builtin_amdgcn_rsq(p);
-    double g = p * y, h = 0.5 * y;
-    double e = fma(-h, g, 0.5);
-    g = fma(g, e, g);
-    h = fma(h, e, h);
-    e = fma(-h, g, 0.5);
-    g = fma(g, e, g);
-    h = fma(h, e, h);
-    const double d = fma(-g, g, p);
-    sq = fma(d, h, g);
-    rs = h + h;
-}
-
-// Factor (DO_CHOL) and invert one 64x64 lower block per workgroup; the
-// workgroup is ONE wave and lane i owns row i of the block in registers.
-//   factor : right-looking, fully unrolled.  Column j: pivot broadcast by
-//            v_readlane, Goldschmidt rsqrt, the finished column goes to LDS
-//            (Lt[j][*], lane-contiguous) and is read back as wave-uniform
-//            broadcasts for the rank-1 update of the lane's row.
-//   invert : lane c solves L x = e_c by right-looking forward substitution, L
-//            read from Lt as broadcasts, x in registers, no cross-lane traffic.
-// jb <= 64 valid rows/cols; the rest is padded with the identity.  Outputs: L
-// (lower, zeros above) written back when DO_CHOL; the inverse goes to Dinv
-// (dense 64x64, ld 64) and/or into inv_out (ld ldi, jb x jb part).
+// DO_CHOL: factor the block in place (jb <= 64 valid rows/cols, identity padding)
+// and report the first non-positive pivot; then (both modes) invert it.  Outputs:
+// the inverse into Dinv (dense 64x64, ld 64, blockIdx-th slab; upper blocks are
+// never written and must be zero) and/or into inv_out (ld ldi, jb x jb part).
 template <bool DO_CHOL>
 __global__ __launch_bounds__(64) void diag_block_kernel(double* __restrict__ Abase, int lda, int n,
                                                         int first_block, double* __restrict__ Dinv,
@@ -57,29 +46,29 @@ __global__ __launch_bounds__(64) void diag_block_kernel(double* __restrict__ Aba
                                                         int* __restrict__ info,
                                                         unsigned long long* __restrict__ stamps) {
     __shared__ double Lt[NB][NB + 1];      // Lt[k][i] = L[i][k]
+    __shared__ double Tl[4][16][17];       // inverses of the 16x16 diagonal blocks, row-major
+    __shared__ double rdiag[NB];           // 1 / L[i][i]
 #define EDRGP_STAMP(slot) do { if (stamps != nullptr && threadIdx.x == 0) stamps[slot] = __builtin_amdgcn_s_memtime(); } while (0)
     EDRGP_STAMP(0);
-    __shared__ double rdiag[NB];           // 1 / L[i][i]
     const int lane = threadIdx.x;
     const int blk = first_block + blockIdx.x;
     const int j0 = blk * NB;
     const int jb = min(NB, n - j0);
     double* A = Abase + (size_t)j0 * lda + j0;
-
-    // coalesced load of the block (all 64 row loads in flight at once), then
-    // transposed into LDS: Lt[c][r] = A[r][c]
     {
-        double t[NB];
         const int cl = min(lane, jb - 1);
+#pragma unroll 1
+        for (int r0 = 0; r0 < NB; r0 += 8) {        // coalesced, clamped (branch-free), 8 rows in flight
+            double t[8];
 #pragma unroll
-        for (int r = 0; r < NB; ++r) t[r] = A[(size_t)min(r, jb - 1) * lda + cl];   // clamped, branch-free
+            for (int u = 0; u < 8; ++u) t[u] = A[(size_t)min(r0 + u, jb - 1) * lda + cl];
 #pragma unroll
-        for (int r = 0; r < NB; ++r) {
-            const bool in = (r < jb) && (lane < jb) && (lane <= r);
-            t[r] = in ? t[r] : ((r == lane) ? 1.0 : 0.0);
+            for (int u = 0; u < 8; ++u) {
+                const int r = r0 + u;
+                const bool in = (r < jb) && (lane < jb) && (lane <= r);
+                Lt[lane][r] = in ? t[u] : ((r == lane) ? 1.0 : 0.0);
+            }
         }
-#pragma unroll
-        for (int r = 0; r < NB; ++r) Lt[lane][r] = t[r];
     }
     __syncthreads();
     EDRGP_STAMP(1);
@@ -103,85 +92,105 @@ __global__ __launch_bounds__(64) void diag_block_kernel(double* __restrict__ Aba
             if (lane < j) l = 0.0;
             a[j] = l;
             if (j + 1 < NB) {
-                // critical path first: the next pivot column needs only l[j+1] (one readlane)
+                // critical path first: the next pivot needs only l[j+1] (one readlane)
                 const double cn = readlane_f64(l, j + 1);
                 a[j + 1] = fma(-l, cn, a[j + 1]);
             }
             Lt[j][lane] = l;
             if (lane == j) rdiag[j] = y;
             __syncthreads();
-            // bulk of the rank-1 update from wave-uniform LDS reads (v_readlane per
-            // element measured 4x slower than the LDS broadcast for a lone wave)
 #pragma unroll
             for (int k = j + 2; k < NB; ++k) a[k] = fma(-l, Lt[j][k], a[k]);
         }
         if (bad && lane == 0 && info != nullptr) atomicCAS(info, 0, bad);
         __syncthreads();
         EDRGP_STAMP(2);
-        // coalesced write-back of L (lower part, explicit zeros above)
-        for (int r = 0; r < jb; ++r)
+#pragma unroll 1
+        for (int r = 0; r < jb; ++r)               // coalesced write-back, explicit zeros above the diagonal
             if (lane < jb) A[(size_t)r * lda + lane] = (lane <= r) ? Lt[lane][r] : 0.0;
-        EDRGP_STAMP(3);
     } else {
         rdiag[lane] = 1.0 / Lt[lane][lane];
         __syncthreads();
-        EDRGP_STAMP(3);
+        EDRGP_STAMP(2);
     }
+    EDRGP_STAMP(3);
 
-    // inverse: lane c owns column c of X = L^-1.  Right-looking forward
-    // substitution: once x_k is final, every later row's accumulator takes its
-    // L[i][k] x_k term -- 63-k independent FMAs per step; column k of L is read
-    // from LDS as wave-uniform broadcasts, prefetched one column ahead.
+    // ---- inverse, step 1: T_b = inv(L_bb) for the four 16x16 diagonal blocks
     {
-        double x[NB];
+        const int b = lane >> 4, cidx = lane & 15, o = 16 * b;
+        double t[16];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) x[i] = (i == lane) ? 1.0 : 0.0;
-        double la[NB], lb[NB];             // column k of L (rows k+1..63), two-stage ring
+        for (int i = 0; i < 16; ++i) t[i] = (i == cidx) ? 1.0 : 0.0;
 #pragma unroll
-        for (int i = 1; i < NB; ++i) la[i] = Lt[0][i];
+        for (int k = 0; k < 16; ++k) {
+            t[k] *= rdiag[o + k];
+            const double tk = t[k];
 #pragma unroll
-        for (int k = 0; k < NB; k += 2) {
-            // prefetch column k+1 while column k is consumed, and vice versa
-#pragma unroll
-            for (int i = k + 2; i < NB; ++i) lb[i] = Lt[k + 1][i];
-            __builtin_amdgcn_sched_barrier(0);
-            x[k] *= rdiag[k];
-            {
-                const double xk = x[k];
-#pragma unroll
-                for (int i = k + 1; i < NB; ++i) x[i] = fma(-la[i], xk, x[i]);
-            }
-            if (k + 2 < NB) {
-#pragma unroll
-                for (int i = k + 3; i < NB; ++i) la[i] = Lt[k + 2][i];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            x[k + 1] *= rdiag[k + 1];
-            {
-                const double xk = x[k + 1];
-#pragma unroll
-                for (int i = k + 2; i < NB; ++i) x[i] = fma(-lb[i], xk, x[i]);
-            }
+            for (int i = k + 1; i < 16; ++i) t[i] = fma(-Lt[o + k][o + i], tk, t[i]);    // L_bb[i][k]
         }
-        EDRGP_STAMP(4);
-        if (Dinv) {
-            double* D = Dinv + (size_t)blockIdx.x * NB * NB;
 #pragma unroll
-            for (int i = 0; i < NB; ++i) D[i * NB + lane] = x[i];
-        }
-        if (inv_out) {
-            double* O = inv_out + (size_t)j0 * ldi + j0;
+        for (int i = 0; i < 16; ++i) Tl[b][i][cidx] = t[i];
+    }
+    __syncthreads();
+
+    // ---- inverse, step 2: block substitution on the matrix pipe
+    const int lr = lane & 15, lq = lane >> 4;
+    d4 X[4][4];                                   // X[i][j], i >= j, C/D layout: reg r = row lq + 4r, col lr
 #pragma unroll
-            for (int i = 0; i < NB; ++i)
-                if (i < jb && lane < jb) O[(size_t)i * ldi + lane] = x[i];
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) X[j][j][r] = Tl[j][lq + 4 * r][lr];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+#pragma unroll
+        for (int i = j + 1; i < 4; ++i) {
+            d4 S = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = j; k < i; ++k)
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    // A fragment of L_ik: lane holds L[16i + lr][16k + 4 st + lq]
+                    const double af = Lt[16 * k + 4 * st + lq][16 * i + lr];
+                    S = __builtin_amdgcn_mfma_f64_16x16x4f64(af, X[k][j][st], S, 0, 0, 0);
+                }
+            d4 Y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const double tf = -Tl[i][lr][4 * st + lq];          // A fragment of -T_ii
+                Y = __builtin_amdgcn_mfma_f64_16x16x4f64(tf, S[st], Y, 0, 0, 0);
+            }
+            X[i][j] = Y;
         }
+    }
+    EDRGP_STAMP(4);
+    if (Dinv) {
+        double* D = Dinv + (size_t)blockIdx.x * NB * NB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = j; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) D[(16 * i + lq + 4 * r) * NB + 16 * j + lr] = X[i][j][r];
+    }
+    if (inv_out) {
+        double* O = inv_out + (size_t)j0 * ldi + j0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = j; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * i + lq + 4 * r, col = 16 * j + lr;
+                    if (row < jb && col < jb) O[(size_t)row * ldi + col] = X[i][j][r];
+                }
     }
     EDRGP_STAMP(5);
 #undef EDRGP_STAMP
 }
 
-// one factor+invert of a 64x64 block with phase stamps (shader cycles): diagnostic only
+// one factor+invert of a 64x64 block with phase stamps: diagnostic only
 int diag_block_stamps(Ctx* c, double* A64, double* Dinv64, unsigned long long* stamps_dev, int do_chol) {
+    HIP_TRY(hipMemsetAsync(Dinv64, 0, NB * NB * sizeof(double), c->stream));
     if (do_chol)
         hipLaunchKernelGGL(diag_block_kernel<true>, dim3(1), dim3(64), 0, c->stream, A64, 64, 64, 0, Dinv64,
                            (double*)nullptr, 0, (int*)nullptr, stamps_dev);
@@ -213,7 +222,11 @@ __global__ void fill_kernel(double* __restrict__ A, size_t count, double v) {
 
 int potrf_lower(Ctx* c, double* A, int n, int lda, int* info_dev) {
     HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), c->stream));
-    TRY(c->dinv.reserve((size_t)NB * NB * sizeof(double)));
+    if (c->dinv.bytes < (size_t)NB * NB * sizeof(double)) {
+        TRY(c->dinv.reserve((size_t)NB * NB * sizeof(double)));
+        // blocks above the diagonal are never written by the kernel
+        HIP_TRY(hipMemsetAsync(c->dinv.d(), 0, (size_t)NB * NB * sizeof(double), c->stream));
+    }
     double* Dinv = c->dinv.d();
     const int nblk = (n + NB - 1) / NB;
     for (int b = 0; b < nblk; ++b) {
@@ -228,12 +241,14 @@ int potrf_lower(Ctx* c, double* A, int n, int lda, int* info_dev) {
             // panel (one column tile) and has consumed them before its epilogue stores.
             GemmOpts po;
             po.force_tile = 64;
+            po.kmode = K_LE_COL;                 // Dinv is lower triangular
             TRY(gemm(c, false, true, rem, jb, jb, 1.0, A21, lda, Dinv, NB, 0.0, A21, lda, po));
-            // A22 -= L21 L21^T on the lower tiles
+            // A22 -= L21 L21^T on the lower 64x64 tiles (K = 64: many small workgroups
+            // beat few large ones here -- 14 us vs 38 us per update)
             double* A22 = A + (size_t)(j0 + jb) * lda + (j0 + jb);
             GemmOpts o;
             o.tri = 1;
-            o.force_tile = (rem >= 1024) ? 128 : 64;
+            o.force_tile = 64;
             TRY(gemm(c, false, true, rem, rem, jb, -1.0, A21, lda, A21, lda, 1.0, A22, lda, o));
         }
     }

@@ -81,7 +81,8 @@ int  edrgp_ctx_create(int device, edrgp_ctx** ctx);
 int  edrgp_ctx_destroy(edrgp_ctx* ctx);
 int  edrgp_sync(edrgp_ctx* ctx);
 /* tunables: "chunk_rows", "syrk_splits", "profile" (0/1), "stats_mode" (0 auto,
- * 1 Gram form Phi = K_mn K_nm, 2 stable form via K_nm Lm^-T), "pivot_ratio_max" */
+ * 1 Gram form Phi = K_mn K_nm, 2 stable form via K_nm Lm^-T), "pivot_ratio_max",
+ * "overlap" (0/1: run the O(M^3) phases on a side stream beside the row passes) */
 int  edrgp_set_option(edrgp_ctx* ctx, const char* key, double value);
 
 /* Training data (already validated / normalised by the host: check_X_y at

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--mode", type=int, default=0)
     ap.add_argument("--splits", type=int, default=0)
+    ap.add_argument("--overlap", type=int, default=1)
     a = ap.parse_args()
     X, y, Z = synthetic(a.N, a.D, a.M)
     h = HipGP(0)
@@ -37,6 +38,7 @@ def main():
     out = {"calib_mfma_f64_tflops": tf, "calib_hbm_copy_gbps": bw, "N": a.N, "M": a.M, "D": a.D}
     h.set_option("stats_mode", a.mode)
     h.set_option("syrk_splits", a.splits)
+    h.set_option("overlap", a.overlap)
     h.set_data(X, y)
     h.set_inducing(Z)
     h.set_kernel([a.kind], [1.0], np.full((1, a.D), np.sqrt(a.D)), 0.01)
@@ -54,6 +56,12 @@ def main():
         prof = {k: h.profile_get(k) for k in ("SYRK", "KBUILD", "GRADGEMM", "SMALL")}
         out[name] = {"ms": dt * 1e3, "prof_ms_per_call": {k: v[0] / a.reps for k, v in prof.items()},
                      "launches": {k: v[1] / a.reps for k, v in prof.items()}}
+    h.set_option("trace", 1)
+    t0 = time.perf_counter(); h.sparse_lml_grad(); t1 = time.perf_counter()
+    sys.stderr.write("python-side lml_grad wall %.3f ms\n" % ((t1 - t0) * 1e3))
+    t0 = time.perf_counter(); h.predict_train(); t1 = time.perf_counter()
+    sys.stderr.write("python-side predict_train wall %.3f ms\n" % ((t1 - t0) * 1e3))
+    h.set_option("trace", 0)
     syrk_ms = out["lml"]["prof_ms_per_call"]["SYRK"]
     flops = a.N * a.M * (a.M + 1.0)
     out["syrk_tflops_algorithmic"] = flops / (syrk_ms * 1e-3) * 1e-12
