@@ -9,6 +9,7 @@
 #include <cstring>
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 
 namespace edrgp {
 
@@ -759,6 +760,7 @@ int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
     else if (!std::strcmp(key, "pivot_ratio_max")) c->pivot_ratio_max = value;
     else if (!std::strcmp(key, "overlap")) c->overlap = (value != 0.0);
     else if (!std::strcmp(key, "trace")) c->trace = (value != 0.0);
+    else if (!std::strcmp(key, "gemm_dephase")) c->gemm_dephase = (int)value;
     else { set_error("unknown option %s", key); return EDRGP_ERR_INVALID; }
     return EDRGP_OK;
 }
@@ -1055,7 +1057,8 @@ int edrgp_dbg_syrk_variant(edrgp_ctx* ctx, int64_t N, int M, int variant, int sp
     if (N <= 0 || N % 16 || M % 128 || reps < 1) { set_error("dbg_syrk_variant: need N %% 16 == 0, M %% 128 == 0"); return EDRGP_ERR_INVALID; }
     TRY(c->Knm.reserve((size_t)N * M * sizeof(double)));
     TRY(c->mats[MAT_PHI].reserve(((size_t)M * M + M + 8) * sizeof(double)));
-    TRY(fill_pattern(c, c->Knm.d(), (size_t)N * M, 12345ULL));
+    TRY(fill_pattern(c, c->Knm.d(), (size_t)N * M, splits < 0 ? 0ULL : 12345ULL));   // splits < 0: constant data probe
+    if (splits < 0) splits = 0;
     double* Phi = c->mats[MAT_PHI].d();
     const int saved = c->syrk_splits;
     c->syrk_splits = splits;
@@ -1124,6 +1127,12 @@ int edrgp_dbg_mfma_layout(edrgp_ctx* ctx, const double* A16x4, const double* B4x
 
 int edrgp_calib(edrgp_ctx* ctx, double* mfma_f64_tflops, double* hbm_copy_gbps) {
     CTX(ctx);
+    if (getenv("EDRGP_CALIB_PATTERNS")) {
+        double t[8] = {0};
+        TRY(calib_mfma_patterns(c, t));
+        fprintf(stderr, "[calib] 2 waves/SIMD: 4x4 grid %.1f | AGPR acc %.1f | one A/B pair %.1f | +LDS frag reads %.1f | +global loads %.1f TF;"
+                        " 1 wave/SIMD: 4x4 grid %.1f | +LDS frag reads %.1f TF\n", t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
+    }
     if (mfma_f64_tflops) TRY(calib_mfma_f64(c, mfma_f64_tflops));
     if (hbm_copy_gbps) TRY(calib_hbm_copy(c, hbm_copy_gbps));
     return EDRGP_OK;

@@ -24,6 +24,90 @@ __global__ __launch_bounds__(256) void mfma_f64_rate_kernel(int iters, double* s
     if (s[0] + s[1] + s[2] + s[3] == -1.0) sink[0] = s[0];   // never true; keeps the chain live
 }
 
+// Issue-pattern probes: P=1: 4x4 accumulator grid, distinct A/B registers, VGPR accumulators;
+// P=2: same with AGPR accumulators; P=3: 16 accumulators, one A/B pair.
+#define MFMA_V(acc, a, b) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#define MFMA_A(acc, a, b) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
+template <int P>
+__global__ __launch_bounds__(256, 2) void mfma_pattern_kernel(int iters, double* sink, const double* __restrict__ gsrc) {
+    __shared__ double lds[16][144];
+    const int lane = threadIdx.x & 63;
+    const int lr = lane & 15, lq = lane >> 4;
+    for (int i = threadIdx.x; i < 16 * 144; i += 256) lds[i / 144][i % 144] = 1.0 + 1e-6 * i;
+    __syncthreads();
+    double a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = 1.0 + 1e-3 * (lane + i); b[i] = 1.0 - 1e-3 * (lane + 2 * i); }
+    d4 acc[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] = d4{0, 0, 0, 0};
+    const double* gp = gsrc + (size_t)(blockIdx.x % 64) * 4096 + lane;
+    for (int i = 0; i < iters; ++i) {
+        if (P == 4) {            // 8 LDS fragment reads per 16 MFMAs, as the GEMM inner loop does
+            const int kk = i & 3;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { a[x] = lds[kk * 4 + lq][x * 16 + lr]; b[x] = lds[kk * 4 + lq][64 + x * 16 + lr]; }
+        }
+        if (P == 5) {            // 8 global loads (L2-resident) per 16 MFMAs
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { a[x] = gp[((i & 7) * 8 + x) * 64]; b[x] = gp[((i & 7) * 8 + 4 + x) * 64]; }
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                if (P == 2) MFMA_A(acc[x][y], a[x], b[y]);
+                else if (P == 3) MFMA_V(acc[x][y], a[0], b[0]);
+                else MFMA_V(acc[x][y], a[x], b[y]);
+            }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15");
+    d4 s = {0, 0, 0, 0};
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) s += acc[x][y];
+    if (s[0] + s[1] + s[2] + s[3] == -1.0) sink[0] = s[0];
+}
+
+int calib_mfma_patterns(Ctx* c, double* tflops8) {
+    TRY(c->red.reserve(64));
+    DBuf g;
+    TRY(g.reserve((size_t)64 * 4096 * 2 * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(g.p, 0, g.bytes, c->stream));
+    const int iters = 2500;
+    // P: 1 = 4x4 grid VGPR acc, 2 = AGPR acc, 3 = one A/B pair, 4 = + LDS fragment reads, 5 = + global loads,
+    //    6 = pattern 1 with ONE wave per SIMD, 7 = pattern 4 with one wave per SIMD
+    for (int P = 1; P <= 7; ++P) {
+        const int blocks = (P >= 6) ? c->num_cu : c->num_cu * 2;
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        for (int rep = 0; rep < 2; ++rep) {
+            if (rep == 1) HIP_TRY(hipEventRecord(e0, c->stream));
+            const double* gs = g.d();
+            switch (P) {
+                case 1: case 6: hipLaunchKernelGGL(mfma_pattern_kernel<1>, dim3(blocks), dim3(256), 0, c->stream, iters, c->red.d(), gs); break;
+                case 2: hipLaunchKernelGGL(mfma_pattern_kernel<2>, dim3(blocks), dim3(256), 0, c->stream, iters, c->red.d(), gs); break;
+                case 3: hipLaunchKernelGGL(mfma_pattern_kernel<3>, dim3(blocks), dim3(256), 0, c->stream, iters, c->red.d(), gs); break;
+                case 4: case 7: hipLaunchKernelGGL(mfma_pattern_kernel<4>, dim3(blocks), dim3(256), 0, c->stream, iters, c->red.d(), gs); break;
+                default: hipLaunchKernelGGL(mfma_pattern_kernel<5>, dim3(blocks), dim3(256), 0, c->stream, iters, c->red.d(), gs); break;
+            }
+        }
+        HIP_TRY(hipEventRecord(e1, c->stream));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        tflops8[P] = (double)blocks * 4.0 * iters * 16.0 * 2048.0 / (ms * 1e-3) * 1e-12;
+    }
+    g.release();
+    return EDRGP_OK;
+}
+
 int calib_mfma_f64(Ctx* c, double* tflops) {
     TRY(c->red.reserve(64));
     const int iters = 10000;

@@ -143,6 +143,7 @@ int predict_chunk(Ctx* c, const KSpec& ks, const double* Xs, int64_t rows, const
                   double* GT, double* mean, double* var, double* jac);
 int vec_axpy(Ctx* c, int64_t n, double a, const double* x, double* y);   // y += a x
 int calib_mfma_f64(Ctx* c, double* tflops);
+int calib_mfma_patterns(Ctx* c, double* tflops4);
 int calib_hbm_copy(Ctx* c, double* gbps);
 int mfma_layout_probe(Ctx* c, const double* A, const double* B, double* C);  // device ptrs
 
@@ -154,6 +155,7 @@ struct Ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DBuf red2, slabs2;                    // scratch used while launching on the side stream
     bool overlap = true;
+    int gemm_dephase = 3;             // see la_gemm.hip: 3 = staging / barrier phases at raised priority
     bool trace = false;
     int num_cu = 256;
 

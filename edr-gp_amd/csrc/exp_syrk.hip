@@ -2,6 +2,7 @@
 // LDS-staged kernel (la_gemm.hip).  Reached only through edrgp_dbg_syrk_variant.
 // Aligned shapes only: M % 128 == 0, rows % 16 == 0, ld even.
 #include "common.h"
+#include <cstdlib>
 
 namespace edrgp {
 
@@ -13,7 +14,8 @@ __global__ void fill_pattern_kernel(double* __restrict__ K, size_t n, unsigned l
     for (; i < n; i += stride) {
         unsigned long long x = (i + 1) * 0x9E3779B97F4A7C15ULL + seed;
         x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 32;
-        K[i] = (double)(x >> 11) * (1.0 / 9007199254740992.0);        // uniform [0, 1) like kernel values
+        // seed 0: constant operands (lowest switching activity); otherwise uniform [0, 1) like kernel values
+        K[i] = (seed == 0ULL) ? 0.5 : (double)(x >> 11) * (1.0 / 9007199254740992.0);
     }
 }
 
@@ -34,7 +36,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nt) {
 template <int KS>   // k-steps (of 4 rows) per stage
 __global__ __launch_bounds__(256, 2) void syrk_direct_kernel(const double* __restrict__ K, int rows, int M, int ld,
                                                              double* __restrict__ slabs, long long slabStride,
-                                                             int splits) {
+                                                             int splits, unsigned long long* __restrict__ clk) {
+    unsigned long long t_cyc0 = 0, t_real0 = 0;
+    const bool stamp = (clk != nullptr) && (threadIdx.x == 0) && (blockIdx.x == 3) && (blockIdx.y == 1);
+    if (stamp) { t_cyc0 = __builtin_amdgcn_s_memtime(); t_real0 = __builtin_amdgcn_s_memrealtime(); }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 15, lq = lane >> 4;
@@ -85,6 +90,10 @@ __global__ __launch_bounds__(256, 2) void syrk_direct_kernel(const double* __res
             compute(a1, b1);
         }
     }
+    if (stamp) {       // diagnostic: shader cycles and 100 MHz real-time ticks over the k-loop of one workgroup
+        clk[0] = __builtin_amdgcn_s_memtime() - t_cyc0;
+        clk[1] = __builtin_amdgcn_s_memrealtime() - t_real0;
+    }
     double* C = slabs + (long long)blockIdx.y * slabStride;
 #pragma unroll
     for (int x = 0; x < 4; ++x)
@@ -106,11 +115,21 @@ int syrk_variant(Ctx* c, const double* K, int rows, int M, int ld, int variant, 
     const long long slabStride = (long long)M * M;
     TRY(c->slabs.reserve((size_t)splits * slabStride * sizeof(double)));
     dim3 grid((unsigned)nt, (unsigned)splits);
-    if (variant == 1) hipLaunchKernelGGL((syrk_direct_kernel<2>), grid, dim3(256), 0, c->stream, K, rows, M, ld, c->slabs.d(), slabStride, splits);
-    else if (variant == 2) hipLaunchKernelGGL((syrk_direct_kernel<1>), grid, dim3(256), 0, c->stream, K, rows, M, ld, c->slabs.d(), slabStride, splits);
+    TRY(c->red.reserve(64));
+    unsigned long long* clk = static_cast<unsigned long long*>(c->red.p);
+    if (variant == 1) hipLaunchKernelGGL((syrk_direct_kernel<2>), grid, dim3(256), 0, c->stream, K, rows, M, ld, c->slabs.d(), slabStride, splits, clk);
+    else if (variant == 2) hipLaunchKernelGGL((syrk_direct_kernel<1>), grid, dim3(256), 0, c->stream, K, rows, M, ld, c->slabs.d(), slabStride, splits, clk);
     else { set_error("unknown syrk variant %d", variant); return EDRGP_ERR_INVALID; }
     HIP_TRY(hipGetLastError());
     if (Phi) TRY(slab_reduce_mirror(c, c->slabs.d(), splits, slabStride, M, Phi));
+    if (getenv("EDRGP_CLK")) {
+        unsigned long long h[2] = {0, 0};
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost));
+        const int ksteps = (rows / 4 + splits - 1) / splits;
+        fprintf(stderr, "[clk] variant %d: %llu shader cycles, %llu x10ns -> %.3f GHz; %d k-steps -> %.1f cycles per k-step (16 MFMA per wave)\n",
+                variant, h[0], h[1], h[1] ? (double)h[0] / (double)h[1] * 0.1 : 0.0, ksteps, (double)h[0] / ksteps);
+    }
     return EDRGP_OK;
 }
 

@@ -18,6 +18,7 @@
 //   B operand: lane l holds B[k = l>>4][j = l&15]
 //   C/D      : reg r of lane l is C[row = (l>>4) + 4r][col = l&15]
 #include "common.h"
+#include <cstdlib>
 
 namespace edrgp {
 
@@ -38,6 +39,8 @@ struct GemmArgs {
     long long slabStride;
     int tiles_m, tiles_n, tri;
     int vecA, vecB;
+    unsigned long long* stamps;   // TAG 9 only
+    int dephase;        // 0 none; 1 s_setprio on odd wave slots; 2 half-tile start delay on odd wave slots
     int kmode;          // triangular operands: bit0 k <= row tile end, bit1 k >= row tile start,
                         //                      bit2 k <= col tile end, bit3 k >= col tile start
 };
@@ -82,24 +85,54 @@ struct TileLoader {
         }
     }
 
-    __device__ __forceinline__ void store(double (*S)[BMN + LPAD], int tid) const {
+    // Interior fast path.  Measured on gfx950: while the SIMD's other wave streams
+    // f64 MFMAs, this wave's VALU instructions issue about once per MFMA (~64
+    // cycles each), so the ~100 address / bounds instructions of the guarded loader
+    // cost ~5300 cycles per k-tile.  Here the per-thread byte offsets inside a k-tile
+    // are computed once (32-bit), the tile base is wave-uniform (SGPR pair, advanced
+    // with SALU): the loop body is NV global_load_dwordx4 and nothing else.
+    // byte offsets relative to the tile origin (tile_origin below), < 2^31 by the caller's check
+    __device__ __forceinline__ void offsets(unsigned (&off)[NV], int ld, int tid) const {
         if (KM) {
             constexpr int TPR = BMN / 2;
             constexpr int RPP = 256 / TPR;
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const int kl = v * RPP + tid / TPR;
-                const int il = (tid % TPR) * 2;
-                *reinterpret_cast<double2*>(&S[kl][il]) = r[v];
-            }
+            for (int v = 0; v < NV; ++v) off[v] = (unsigned)(((v * RPP + tid / TPR) * ld + (tid % TPR) * 2) * 8);
         } else {
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const int il = v * 32 + tid / 8;
-                const int kl = (tid % 8) * 2;
-                S[kl][il] = r[v].x;
-                S[kl + 1][il] = r[v].y;
-            }
+            for (int v = 0; v < NV; ++v) off[v] = (unsigned)(((v * 32 + tid / 8) * ld + (tid % 8) * 2) * 8);
+        }
+    }
+    // element offset of k-tile `kt` of the operand tile starting at row/col mn0
+    static __device__ __forceinline__ long long tile_origin(int ld, int mn0, int kt) {
+        return KM ? (long long)kt * BK * ld + mn0 : (long long)mn0 * ld + (long long)kt * BK;
+    }
+    // bytes from one k-tile to the next
+    static __device__ __forceinline__ long long tile_step(int ld) { return KM ? (long long)BK * ld * 8 : (long long)BK * 8; }
+
+    __device__ __forceinline__ void load_fast(const char* __restrict__ tile_base, const unsigned (&off)[NV]) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) r[v] = *reinterpret_cast<const double2*>(tile_base + off[v]);
+    }
+
+    // LDS image of one operand k-tile.  k-major sources keep [k][m] rows (stride BMN+16
+    // doubles); m-major sources keep their own [m][k] rows (stride BK+2 doubles), so both
+    // are filled with 16-byte stores and both give conflict-free ds_read_b64 fragments
+    // (bank sets of the 16 rows x 4 k of a fragment are disjoint for either stride).
+    static constexpr int SIZE = KM ? BK * (BMN + LPAD) : BMN * (BK + 2);
+    static __device__ __forceinline__ int idx(int k, int m) { return KM ? k * (BMN + LPAD) + m : m * (BK + 2) + k; }
+
+    __device__ __forceinline__ void store(double* __restrict__ S, int tid) const {
+        if (KM) {
+            constexpr int TPR = BMN / 2;
+            constexpr int RPP = 256 / TPR;
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                *reinterpret_cast<double2*>(&S[idx(v * RPP + tid / TPR, (tid % TPR) * 2)]) = r[v];
+        } else {
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                *reinterpret_cast<double2*>(&S[idx((tid % 8) * 2, v * 32 + tid / 8)]) = r[v];
         }
     }
 };
@@ -110,13 +143,27 @@ template <int BM, int BN, bool AKM, bool BKM, int TAG>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int TM = WM / 16, TN = WN / 16;
-    __shared__ __attribute__((aligned(16))) double As[2][BK][BM + LPAD];
-    __shared__ __attribute__((aligned(16))) double Bs[2][BK][BN + LPAD];
+    typedef TileLoader<BM, AKM> LA;
+    typedef TileLoader<BN, BKM> LB;
+    __shared__ __attribute__((aligned(16))) double As[2][LA::SIZE];
+    __shared__ __attribute__((aligned(16))) double Bs[2][LB::SIZE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 15, lq = lane >> 4;
+
+    // Two workgroups share a CU (two waves per SIMD).  Launched together and doing
+    // identical work they run in lockstep, so their barrier / staging phases coincide
+    // and the matrix pipe idles (~20 % measured).  De-phase them by the hardware wave
+    // slot (HW_ID[3:0]), which differs between the two waves of a SIMD: speed only.
+    if (g.dephase) {
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;
+        if (slot) {
+            if (g.dephase == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_sleep(48);
+        }
+    }
 
     // ---- tile id with an XCD-aware (bijective) remap: blocks b, b+8, ... share
     // an XCD (L2), give them consecutive tiles so they share operand panels.
@@ -175,36 +222,85 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         const bool vA = g.vecA, vB = g.vecB;
         TileLoader<BM, AKM> la;
         TileLoader<BN, BKM> lb;
-        la.load(A, g.lda, m0, kt0 * BK, Meff, Keff, vA, tid);
-        lb.load(B, g.ldb, n0, kt0 * BK, g.N, Keff, vB, tid);
+        // interior workgroup: full tile, full k-tiles, 16-byte aligned rows, 32-bit tile footprint
+        const bool fast = vA && vB && (m0 + BM <= Meff) && (n0 + BN <= g.N) && (kt1 * BK <= Keff) &&
+                          ((long long)(AKM ? BK : BM) * g.lda < (1LL << 28)) &&
+                          ((long long)(BKM ? BK : BN) * g.ldb < (1LL << 28));
+        unsigned offA[TileLoader<BM, AKM>::NV], offB[TileLoader<BN, BKM>::NV];
+        const char* baseA = reinterpret_cast<const char*>(A + TileLoader<BM, AKM>::tile_origin(g.lda, m0, kt0));
+        const char* baseB = reinterpret_cast<const char*>(B + TileLoader<BN, BKM>::tile_origin(g.ldb, n0, kt0));
+        const long long stepA = TileLoader<BM, AKM>::tile_step(g.lda), stepB = TileLoader<BN, BKM>::tile_step(g.ldb);
+        if (fast) {
+            la.offsets(offA, g.lda, tid);
+            lb.offsets(offB, g.ldb, tid);
+            la.load_fast(baseA, offA);
+            lb.load_fast(baseB, offB);
+        } else {
+            la.load(A, g.lda, m0, kt0 * BK, Meff, Keff, vA, tid);
+            lb.load(B, g.ldb, n0, kt0 * BK, g.N, Keff, vB, tid);
+        }
         la.store(As[0], tid);
         lb.store(Bs[0], tid);
         __syncthreads();
+        // TAG 9 = diagnostic build of the Phi kernel: per-wave cycle sums of the loop
+        // phases (load issue / MFMA / wait+LDS store / barrier), never used in production
+        unsigned long long st_load = 0, st_mfma = 0, st_store = 0, st_bar = 0, st_t = 0;
+#define GEMM_STAMP(accum)                                                        \
+        if (TAG == 9) {                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                    \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();         \
+            accum += now_ - st_t;                                                 \
+            st_t = now_;                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                    \
+        }
+        if (TAG == 9) st_t = __builtin_amdgcn_s_memtime();
         for (int kt = kt0; kt < kt1; ++kt) {
             const int buf = (kt - kt0) & 1;
             const bool more = (kt + 1 < kt1);
             if (more) {
-                la.load(A, g.lda, m0, (kt + 1) * BK, Meff, Keff, vA, tid);
-                lb.load(B, g.ldb, n0, (kt + 1) * BK, g.N, Keff, vB, tid);
+                if (fast) {
+                    baseA += stepA;
+                    baseB += stepB;
+                    la.load_fast(baseA, offA);
+                    lb.load_fast(baseB, offB);
+                } else {
+                    la.load(A, g.lda, m0, (kt + 1) * BK, Meff, Keff, vA, tid);
+                    lb.load(B, g.ldb, n0, (kt + 1) * BK, g.N, Keff, vB, tid);
+                }
             }
+            GEMM_STAMP(st_load)
+            // dephase 3: the short staging / barrier phases run at raised priority so the
+            // partner wave's MFMA stream cannot starve them; 4: the reverse (T5 style)
+            if (g.dephase == 3) __builtin_amdgcn_s_setprio(0);
+            if (g.dephase == 4) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) {
                 double a[TM], b[TN];
 #pragma unroll
-                for (int x = 0; x < TM; ++x) a[x] = As[buf][kk * 4 + lq][wm * WM + x * 16 + lr];
+                for (int x = 0; x < TM; ++x) a[x] = As[buf][LA::idx(kk * 4 + lq, wm * WM + x * 16 + lr)];
 #pragma unroll
-                for (int x = 0; x < TN; ++x) b[x] = Bs[buf][kk * 4 + lq][wn * WN + x * 16 + lr];
+                for (int x = 0; x < TN; ++x) b[x] = Bs[buf][LB::idx(kk * 4 + lq, wn * WN + x * 16 + lr)];
 #pragma unroll
                 for (int x = 0; x < TM; ++x)
 #pragma unroll
                     for (int y = 0; y < TN; ++y)
                         acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);
             }
+            if (g.dephase == 3) __builtin_amdgcn_s_setprio(2);
+            if (g.dephase == 4) __builtin_amdgcn_s_setprio(0);
+            GEMM_STAMP(st_mfma)
             if (more) {
                 la.store(As[buf ^ 1], tid);
                 lb.store(Bs[buf ^ 1], tid);
             }
+            GEMM_STAMP(st_store)
             __syncthreads();
+            GEMM_STAMP(st_bar)
+        }
+#undef GEMM_STAMP
+        if (TAG == 9 && g.stamps != nullptr && lane == 0 && blockIdx.x == 5 && blockIdx.y == 2) {
+            unsigned long long* o = g.stamps + wave * 4;
+            o[0] = st_load; o[1] = st_mfma; o[2] = st_store; o[3] = st_bar;
         }
     }
 
@@ -250,7 +346,8 @@ __global__ void slab_reduce_kernel(const double* __restrict__ slabs, int splits,
 
 template <int BM, int BN>
 static void launch_variant(bool akm, bool bkm, int tag, dim3 grid, hipStream_t s, const GemmArgs& g) {
-    if (tag == 1 && akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, true, 1>), grid, dim3(256), 0, s, g);
+    if (tag == 9 && akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, true, 9>), grid, dim3(256), 0, s, g);
+    else if (tag == 1 && akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, true, 1>), grid, dim3(256), 0, s, g);
     else if (tag == 2 && !akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, true, 2>), grid, dim3(256), 0, s, g);
     else if (akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, true, 0>), grid, dim3(256), 0, s, g);
     else if (akm && !bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, false, 0>), grid, dim3(256), 0, s, g);
@@ -278,6 +375,12 @@ static int gemm_impl(Ctx* c, bool transA, bool transB, int M, int N, int K, doub
     g.splits = splits;
     g.tri = o.tri;
     g.kmode = o.kmode;
+    g.dephase = c->gemm_dephase;
+    g.stamps = nullptr;
+    if (o.tag == 9) {
+        if (c->red2.reserve(256) != EDRGP_OK) return EDRGP_ERR_HIP;
+        g.stamps = static_cast<unsigned long long*>(c->red2.p);
+    }
     g.tiles_m = (M + tile - 1) / tile;
     g.tiles_n = (N + tile - 1) / tile;
     g.vecA = aligned16(A) && (lda % 2 == 0) && (o.strideA % 2 == 0);
@@ -370,7 +473,7 @@ int syrk_tn(Ctx* c, const double* K, int64_t rows, int M, int ldk, double* Phi, 
     TRY(c->slabs.reserve((size_t)splits * slabStride * sizeof(double)));
     GemmOpts o;
     o.tri = 1;
-    o.tag = 1;
+    o.tag = getenv("EDRGP_GEMM_STAMPS") ? 9 : 1;
     o.force_tile = tile;
     {
         ProfScope ps(c, EDRGP_PROF_SYRK);
@@ -382,6 +485,16 @@ int syrk_tn(Ctx* c, const double* K, int64_t rows, int M, int ldk, double* Phi, 
     hipLaunchKernelGGL(slab_reduce_kernel, grd, blk, 0, c->stream, c->slabs.d(), splits, slabStride, M, M, M,
                        1.0, accumulate ? 1.0 : 0.0, Phi, ldphi, 1);
     HIP_TRY(hipGetLastError());
+    if (o.tag == 9) {
+        unsigned long long h[16];
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(h, c->red2.p, sizeof(h), hipMemcpyDeviceToHost));
+        const double kts = (double)((kt + splits - 1) / splits);
+        for (int w = 0; w < 4; ++w)
+            fprintf(stderr, "[gemm stamps] wave %d: per k-tile cycles: load-issue %.0f  mfma %.0f  wait+lds-store %.0f  barrier %.0f  (total %.0f)\n", w,
+                    h[w * 4] / kts, h[w * 4 + 1] / kts, h[w * 4 + 2] / kts, h[w * 4 + 3] / kts,
+                    (h[w * 4] + h[w * 4 + 1] + h[w * 4 + 2] + h[w * 4 + 3]) / kts);
+    }
     return EDRGP_OK;
 }
 
