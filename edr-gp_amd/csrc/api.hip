@@ -465,6 +465,26 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
             TRY(kernel_matrix(c, ks, c->X.d() + (size_t)r0 * D, rows, c->Z.d(), M, c->Knm.d(), M, 0, 0.0, nullptr,
                               nullptr));
         }
+        const bool fused = (np == 1) && (D <= 32) && c->fuse_grad;
+        if (fused) {
+            // T = (K_nm S2 + beta y wv^T) .* h(r) and the d/dvariance partials straight out of
+            // the contraction's epilogue: no W round trip, no separate element-wise pass
+            ProfScope ps(c, EDRGP_PROF_GRADGEMM);
+            const int ntiles = (int)(((rows + 127) / 128) * ((M + 127) / 128));
+            TRY(c->red.reserve((size_t)ntiles * sizeof(double)));
+            FuseT f;
+            f.X = c->X.d() + (size_t)r0 * D; f.Z = c->Z.d(); f.y = c->y.d() + r0; f.wv = v_wv;
+            f.invl = c->invl.d(); f.dvpart = c->red.d(); f.ycoef = beta; f.var = c->var[0]; f.D = D; f.kind = c->kind[0];
+            GemmOpts o;
+            o.tag = 2;
+            o.force_tile = 128;
+            o.fuse = &f;
+            TRY(gemm(c, false, false, (int)rows, M, M, 1.0, c->Knm.d(), M, S2, M, 0.0, c->T.d(), M, o));
+            TRY(sum_into(c, c->red.d(), ntiles, sc + SC_DVAR_NM));
+            TRY(gemm(c, true, false, M, Wd, (int)rows, 1.0, c->T.d(), M, c->Xt.d() + (size_t)r0 * Wd, Wd,
+                     ch > 0 ? 1.0 : 0.0, c->gt_nm.d(), Wd));
+            continue;
+        }
         {
             ProfScope ps(c, EDRGP_PROF_GRADGEMM);
             GemmOpts o;
@@ -761,6 +781,7 @@ int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
     else if (!std::strcmp(key, "overlap")) c->overlap = (value != 0.0);
     else if (!std::strcmp(key, "trace")) c->trace = (value != 0.0);
     else if (!std::strcmp(key, "gemm_dephase")) c->gemm_dephase = (int)value;
+    else if (!std::strcmp(key, "fuse_grad")) c->fuse_grad = (value != 0.0);
     else { set_error("unknown option %s", key); return EDRGP_ERR_INVALID; }
     return EDRGP_OK;
 }

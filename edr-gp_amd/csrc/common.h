@@ -64,7 +64,22 @@ struct ProfScope {                   // records start/stop events on ctx->stream
 };
 
 // ------------------------------------------------------------------------ GEMM
+// Fused epilogue of the gradient contraction (single-part kernels): instead of
+// W = K_nm S2 the kernel stores T = (W + ycoef y wv^T) .* h(r) and per-workgroup
+// partial sums of (W + ycoef y wv^T) .* k / var  (Stationary.update_gradients_full).
+struct FuseT {
+    const double* X;        // rows x D   (rows of this chunk)
+    const double* Z;        // M x D
+    const double* y;        // rows
+    const double* wv;       // M
+    const double* invl;     // D
+    double* dvpart;         // one partial per workgroup
+    double ycoef, var;
+    int D, kind;
+};
+
 struct GemmOpts {
+    const FuseT* fuse = nullptr;             // tag 2 only
     int tag = 0;                             // kernel symbol tag: 0 generic, 1 Phi syrk, 2 gradient W = K S
     int batch = 1;
     long long strideA = 0, strideB = 0, strideC = 0;
@@ -136,6 +151,7 @@ int grad_elementwise(Ctx* c, const KSpec& ks, int part, const double* X, const d
                      double* T, int ldt, double* dvar_accum /* device scalar, += */);
 // Xt = [X | 1 | X.*X]  (rows x (2D+1))
 int build_xtilde(Ctx* c, const double* X, int64_t rows, int D, double* Xt);
+int sum_into(Ctx* c, const double* part, int n, double* accum);   // accum[0] += sum(part), fixed order
 int rowdot(Ctx* c, const double* A, const double* B, int64_t rows, int cols, int ld, double* out);
 // posterior mean / latent variance / mean Jacobian for one device-resident row chunk
 int predict_chunk(Ctx* c, const KSpec& ks, const double* Xs, int64_t rows, const double* P, const double* Pt,
@@ -155,6 +171,7 @@ struct Ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DBuf red2, slabs2;                    // scratch used while launching on the side stream
     bool overlap = true;
+    bool fuse_grad = true;            // fused Q .* h epilogue of the gradient contraction (single-part kernels, D <= 32)
     int gemm_dephase = 3;             // see la_gemm.hip: 3 = staging / barrier phases at raised priority
     bool trace = false;
     int num_cu = 256;

@@ -13,6 +13,7 @@
 //   MODE_T : out = Q .* h_p(r),  Q = W + ycoef * y[n] * wv[m];
 //            dvpart[block] = sum Q .* k_p / var_p
 #include "common.h"
+#include "kfun.h"
 
 namespace edrgp {
 
@@ -42,24 +43,8 @@ struct PairArgs {
     int rows_per_block;
 };
 
-#define SQRT3 1.7320508075688772
-#define SQRT5 2.23606797749979
-
 __device__ __forceinline__ void kfun(int kind, double var, double r2, double& K, double& h) {
-    if (kind == EDRGP_KERN_RBF) {
-        K = var * exp(-0.5 * r2);
-        h = -K;
-    } else if (kind == EDRGP_KERN_MATERN32) {
-        const double r = sqrt(r2);
-        const double e = exp(-SQRT3 * r);
-        K = var * (1.0 + SQRT3 * r) * e;
-        h = -3.0 * var * e;
-    } else {
-        const double r = sqrt(r2);
-        const double e = exp(-SQRT5 * r);
-        K = var * (1.0 + SQRT5 * r + (5.0 / 3.0) * r2) * e;
-        h = -(5.0 / 3.0) * var * (1.0 + SQRT5 * r) * e;
-    }
+    edrgp_kfun(kind, var, r2, K, h);
 }
 
 template <int MODE>
@@ -253,6 +238,12 @@ __global__ __launch_bounds__(256) void sum_add_kernel(const double* __restrict__
         __syncthreads();
     }
     if (threadIdx.x == 0) accum[0] += sh[0];
+}
+
+int sum_into(Ctx* c, const double* part, int n, double* accum) {
+    hipLaunchKernelGGL(sum_add_kernel, dim3(1), dim3(256), 0, c->stream, part, n, accum);
+    HIP_TRY(hipGetLastError());
+    return EDRGP_OK;
 }
 
 int grad_elementwise(Ctx* c, const KSpec& ks, int part, const double* X, const double* y, int64_t rows,

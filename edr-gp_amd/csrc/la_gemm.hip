@@ -18,6 +18,7 @@
 //   B operand: lane l holds B[k = l>>4][j = l&15]
 //   C/D      : reg r of lane l is C[row = (l>>4) + 4r][col = l&15]
 #include "common.h"
+#include "kfun.h"
 #include <cstdlib>
 
 namespace edrgp {
@@ -40,6 +41,8 @@ struct GemmArgs {
     int tiles_m, tiles_n, tri;
     int vecA, vecB;
     unsigned long long* stamps;   // TAG 9 only
+    FuseT fuse;                   // TAG 2 only, used when fuse_on
+    int fuse_on;
     int dephase;        // 0 none; 1 s_setprio on odd wave slots; 2 half-tile start delay on odd wave slots
     int kmode;          // triangular operands: bit0 k <= row tile end, bit1 k >= row tile start,
                         //                      bit2 k <= col tile end, bit3 k >= col tile start
@@ -304,6 +307,89 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         }
     }
 
+    // ---- fused gradient epilogue (TAG 2): T = (acc + ycoef y wv^T) .* h(r), sum Q .* k / var
+    if (TAG == 2 && g.fuse_on) {
+        // scaled inputs of this tile's rows / columns, staged in the (now idle) operand LDS:
+        // Xs[q][BM] = X[m0 + i][q] * invl[q], Zs[q][BN] = Z[n0 + j][q] * invl[q]
+        constexpr int DC = 32;                               // feature chunk
+        static_assert(2 * LA::SIZE >= DC * BM && 2 * LB::SIZE >= DC * BN, "LDS too small for the fused epilogue");
+        double* Xs = &As[0][0];
+        double* Zs = &Bs[0][0];
+        const FuseT& f = g.fuse;
+        // one feature chunk (the host fuses only when D <= DC): stage, then one row block
+        // of accumulators at a time to keep the register footprint at acc + 16 doubles
+        __syncthreads();
+        for (int e = tid; e < BM * DC; e += 256) {
+            const int i = e / DC, q = e % DC;                // coalesced along the feature dimension
+            double v = 0.0;
+            if (q < f.D && m0 + i < Meff) v = f.X[(size_t)(m0 + i) * f.D + q] * f.invl[q];
+            Xs[q * BM + i] = v;
+        }
+        for (int e = tid; e < BN * DC; e += 256) {
+            const int j = e / DC, q = e % DC;
+            double v = 0.0;
+            if (q < f.D && n0 + j < g.N) v = f.Z[(size_t)(n0 + j) * f.D + q] * f.invl[q];
+            Zs[q * BN + j] = v;
+        }
+        __syncthreads();
+        double wvc[TN];
+#pragma unroll
+        for (int y = 0; y < TN; ++y) {
+            const int col = n0 + wn * WN + y * 16 + lr;
+            wvc[y] = (col < g.N) ? f.wv[col] : 0.0;
+        }
+        double dv = 0.0;
+#pragma unroll
+        for (int x = 0; x < TM; ++x) {
+            double r2[TN][4];
+#pragma unroll
+            for (int y = 0; y < TN; ++y)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) r2[y][r] = 0.0;
+            for (int q = 0; q < f.D; ++q) {
+                double zc[TN], xr[4];
+#pragma unroll
+                for (int y = 0; y < TN; ++y) zc[y] = Zs[q * BN + wn * WN + y * 16 + lr];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xr[r] = Xs[q * BM + wm * WM + x * 16 + lq + 4 * r];
+#pragma unroll
+                for (int y = 0; y < TN; ++y)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double d = xr[r] - zc[y];
+                        r2[y][r] = fma(d, d, r2[y][r]);
+                    }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * WM + x * 16 + lq + 4 * r;
+                const double yr = (row < Meff) ? f.ycoef * f.y[row] : 0.0;
+#pragma unroll
+                for (int y = 0; y < TN; ++y) {
+                    const int col = n0 + wn * WN + y * 16 + lr;
+                    if (row < Meff && col < g.N) {
+                        const double Q = fma(yr, wvc[y], acc[x][y][r]);
+                        double Kv, hv;
+                        edrgp_kfun(f.kind, f.var, r2[y][r], Kv, hv);
+                        dv = fma(Q, Kv, dv);
+                        C[(size_t)row * g.ldc + col] = (r2[y][r] == 0.0) ? 0.0 : Q * hv;
+                    }
+                }
+            }
+        }
+        // fixed-order workgroup reduction of the d/dvariance partial
+        __syncthreads();
+        double* red = &As[0][0];
+        red[tid] = dv;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) red[tid] += red[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) f.dvpart[(size_t)blockIdx.z * gridDim.x + blockIdx.x] = red[0] / f.var;
+        return;
+    }
+
     // ---- epilogue
     const double alpha = g.alpha, beta = g.beta;
 #pragma unroll
@@ -377,6 +463,15 @@ static int gemm_impl(Ctx* c, bool transA, bool transB, int M, int N, int K, doub
     g.kmode = o.kmode;
     g.dephase = c->gemm_dephase;
     g.stamps = nullptr;
+    g.fuse_on = 0;
+    if (o.fuse != nullptr && o.tag == 2) {
+        if (splits != 1 || o.batch != 1 || alpha != 1.0 || beta != 0.0) {
+            set_error("fused gradient epilogue needs an unsplit, unbatched alpha=1 beta=0 product");
+            return EDRGP_ERR_INVALID;
+        }
+        g.fuse = *o.fuse;
+        g.fuse_on = 1;
+    }
     if (o.tag == 9) {
         if (c->red2.reserve(256) != EDRGP_OK) return EDRGP_ERR_HIP;
         g.stamps = static_cast<unsigned long long*>(c->red2.p);
