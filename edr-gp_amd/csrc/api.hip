@@ -14,6 +14,7 @@
 namespace edrgp {
 
 static thread_local std::string g_err;
+static int g_tri_tile = 64;
 
 void set_error(const char* fmt, ...) {
     char buf[1024];
@@ -120,6 +121,8 @@ struct SideStream {
         std::swap(c->stream, c->stream2);
         std::swap(c->red, c->red2);
         std::swap(c->slabs, c->slabs2);
+        std::swap(c->ks_x, c->ks_x2);          // the side stream builds Kmm while the main one builds K_nm
+        std::swap(c->ks_xn, c->ks_xn2);
     }
     // while active c->stream IS the side stream and c->stream2 the main one
     int start_after_main() {
@@ -148,6 +151,9 @@ static GemmOpts kopt(int kmode, int tri = 0, int tag = 0) {
     o.kmode = kmode;
     o.tri = tri;
     o.tag = tag;
+    // zero-skipping makes the k-range depend on the tile: with one 128x128 tile per CU the
+    // longest tile sets the time, 64x64 tiles (4 per CU, mixed lengths) balance it
+    if (kmode != 0 && tag == 0) o.force_tile = g_tri_tile;
     return o;
 }
 
@@ -749,6 +755,7 @@ int edrgp_ctx_destroy(edrgp_ctx* ctx) {
     for (auto& v : c->tmpvec) v.release();
     c->red2.release();
     c->slabs2.release();
+    for (DBuf* b : {&c->ks_x, &c->ks_z, &c->ks_xn, &c->ks_zn, &c->ks_x2, &c->ks_xn2}) b->release();
     (void)hipEventDestroy(c->ev_fork);
     (void)hipEventDestroy(c->ev_join);
     (void)hipStreamDestroy(c->stream2);
@@ -782,6 +789,8 @@ int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
     else if (!std::strcmp(key, "trace")) c->trace = (value != 0.0);
     else if (!std::strcmp(key, "gemm_dephase")) c->gemm_dephase = (int)value;
     else if (!std::strcmp(key, "fuse_grad")) c->fuse_grad = (value != 0.0);
+    else if (!std::strcmp(key, "tri_tile")) g_tri_tile = (int)value;
+    else if (!std::strcmp(key, "mfma_kbuild")) c->mfma_kbuild = (value != 0.0);
     else { set_error("unknown option %s", key); return EDRGP_ERR_INVALID; }
     return EDRGP_OK;
 }

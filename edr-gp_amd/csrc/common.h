@@ -78,8 +78,23 @@ struct FuseT {
     int D, kind;
 };
 
+// Fused epilogue of the kernel-matrix build (single-part kernels): the GEMM computes the
+// inner products of the scaled inputs, the epilogue turns them into covariances
+//   r2 = max(|x|^2 + |z|^2 - 2 x.z, 0)   (GPy Stationary._unscaled_dist, same clip)
+//   K  = var k(r2)  (+ jitter and r2 := 0 on the diagonal when X2 is X)
+// and, when y is given, per-row-tile partial sums of K^T y.
+struct FuseK {
+    const double* xn;       // rows : |x/l|^2
+    const double* zn;       // cols : |z/l|^2
+    const double* y;        // rows or null
+    double* bpart;          // tiles_m x N partial sums of K^T y (when y)
+    double var, jitter;
+    int kind, same;
+};
+
 struct GemmOpts {
     const FuseT* fuse = nullptr;             // tag 2 only
+    const FuseK* fusek = nullptr;            // tag 3 only
     int tag = 0;                             // kernel symbol tag: 0 generic, 1 Phi syrk, 2 gradient W = K S
     int batch = 1;
     long long strideA = 0, strideB = 0, strideC = 0;
@@ -170,6 +185,8 @@ struct Ctx {
     hipStream_t stream2 = nullptr;        // side stream: latency-bound O(M^3) work beside the row pass
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DBuf red2, slabs2;                    // scratch used while launching on the side stream
+    DBuf ks_x, ks_z, ks_xn, ks_zn, ks_x2, ks_xn2;   // scaled inputs and squared norms for the MFMA kernel build
+    bool mfma_kbuild = true;
     bool overlap = true;
     bool fuse_grad = true;            // fused Q .* h epilogue of the gradient contraction (single-part kernels, D <= 32)
     int gemm_dephase = 3;             // see la_gemm.hip: 3 = staging / barrier phases at raised priority

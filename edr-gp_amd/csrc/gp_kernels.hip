@@ -192,9 +192,63 @@ static int pick_rows_per_block(int64_t rows, int col_tiles) {
     return rpb;
 }
 
+// Xs[n][q] = X[n][q] * invl[q], xn[n] = sum_q Xs[n][q]^2; one thread per row
+__global__ void scale_norm_kernel(const double* __restrict__ X, int64_t rows, int D, const double* __restrict__ invl,
+                                  double* __restrict__ Xs, double* __restrict__ xn) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= rows) return;
+    double s = 0.0;
+    for (int q = 0; q < D; ++q) {
+        const double v = X[n * D + q] * invl[q];
+        Xs[n * D + q] = v;
+        s = fma(v, v, s);
+    }
+    xn[n] = s;
+}
+
+// Single-part kernels: inner products of the scaled inputs on the matrix pipe (NT GEMM over
+// the feature dimension) + covariance epilogue.  |x|^2 + |z|^2 - 2 x.z is GPy's own formula.
+static int kernel_matrix_mfma(Ctx* c, const KSpec& ks, const double* X, int64_t rows, const double* X2, int M2,
+                              double* K, int ldk, int same, double jitter, const double* y, double* bvec) {
+    const int D = ks.D;
+    const bool self = (X2 == X) && (rows == M2);
+    TRY(c->ks_x.reserve((size_t)rows * D * sizeof(double)));
+    TRY(c->ks_xn.reserve((size_t)rows * sizeof(double)));
+    hipLaunchKernelGGL(scale_norm_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, c->stream, X, rows, D,
+                       ks.invl, c->ks_x.d(), c->ks_xn.d());
+    const double* Zs = c->ks_x.d();
+    const double* zn = c->ks_xn.d();
+    if (!self) {
+        TRY(c->ks_z.reserve((size_t)M2 * D * sizeof(double)));
+        TRY(c->ks_zn.reserve((size_t)M2 * sizeof(double)));
+        hipLaunchKernelGGL(scale_norm_kernel, dim3((unsigned)((M2 + 255) / 256)), dim3(256), 0, c->stream, X2,
+                           (int64_t)M2, D, ks.invl, c->ks_z.d(), c->ks_zn.d());
+        Zs = c->ks_z.d();
+        zn = c->ks_zn.d();
+    }
+    const int tile = (rows >= 128 && M2 >= 128 && ((rows + 127) / 128) * ((M2 + 127) / 128) >= 96) ? 128 : 64;
+    const int tiles_m = (int)((rows + tile - 1) / tile);
+    FuseK f;
+    f.xn = c->ks_xn.d(); f.zn = zn; f.y = y; f.bpart = nullptr;
+    f.var = ks.var[0]; f.jitter = jitter; f.kind = ks.kind[0]; f.same = same;
+    if (y != nullptr) {
+        TRY(c->bpart.reserve((size_t)tiles_m * M2 * sizeof(double)));
+        f.bpart = c->bpart.d();
+    }
+    GemmOpts o;
+    o.tag = 3;
+    o.force_tile = tile;
+    o.fusek = &f;
+    TRY(gemm(c, false, true, (int)rows, M2, D, 1.0, c->ks_x.d(), D, Zs, D, 0.0, K, ldk, o));
+    if (y != nullptr) TRY(col_reduce(c, c->bpart.d(), tiles_m, M2, bvec));
+    return EDRGP_OK;
+}
+
 int kernel_matrix(Ctx* c, const KSpec& ks, const double* X, int64_t rows, const double* X2, int M2, double* K,
                   int ldk, int same, double jitter, const double* y, double* bvec) {
     if (rows <= 0 || M2 <= 0) return EDRGP_OK;
+    if (c->mfma_kbuild && ks.nparts == 1 && rows <= 0x7fffffffLL)
+        return kernel_matrix_mfma(c, ks, X, rows, X2, M2, K, ldk, same, jitter, y, bvec);
     PairArgs a{};
     a.ks = ks; a.part = 0; a.X = X; a.rows = rows; a.X2 = X2; a.M2 = M2; a.out = K; a.ldo = ldk;
     a.same = same; a.jitter = jitter; a.y = y; a.W = nullptr; a.wv = nullptr; a.dvpart = nullptr;

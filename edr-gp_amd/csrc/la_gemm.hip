@@ -42,6 +42,7 @@ struct GemmArgs {
     int vecA, vecB;
     unsigned long long* stamps;   // TAG 9 only
     FuseT fuse;                   // TAG 2 only, used when fuse_on
+    FuseK fusek;                  // TAG 3 only
     int fuse_on;
     int dephase;        // 0 none; 1 s_setprio on odd wave slots; 2 half-tile start delay on odd wave slots
     int kmode;          // triangular operands: bit0 k <= row tile end, bit1 k >= row tile start,
@@ -307,6 +308,56 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         }
     }
 
+    // ---- fused kernel-matrix epilogue (TAG 3): acc = <x/l, z/l>  ->  K = var k(r2)
+    if (TAG == 3) {
+        const FuseK& f = g.fusek;
+        double zn[TN], bsum[TN];
+#pragma unroll
+        for (int y = 0; y < TN; ++y) {
+            const int col = n0 + wn * WN + y * 16 + lr;
+            zn[y] = (col < g.N) ? f.zn[col] : 0.0;
+            bsum[y] = 0.0;
+        }
+#pragma unroll
+        for (int x = 0; x < TM; ++x)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * WM + x * 16 + lq + 4 * r;
+                const bool rok = row < Meff;
+                const double xn = rok ? f.xn[row] : 0.0;
+                const double yr = (rok && f.y != nullptr) ? f.y[row] : 0.0;
+#pragma unroll
+                for (int y = 0; y < TN; ++y) {
+                    const int col = n0 + wn * WN + y * 16 + lr;
+                    double r2 = fmax(fma(-2.0, acc[x][y][r], xn + zn[y]), 0.0);
+                    const bool diag = f.same && (row == col);
+                    if (diag) r2 = 0.0;
+                    double Kv, hv;
+                    edrgp_kfun(f.kind, f.var, r2, Kv, hv);
+                    if (diag) Kv += f.jitter;
+                    if (rok && col < g.N) {
+                        C[(size_t)row * g.ldc + col] = Kv;
+                        bsum[y] = fma(Kv, yr, bsum[y]);
+                    }
+                }
+            }
+        if (f.y != nullptr) {
+            // column sums over the tile's rows: 8 partials per column (2 row-waves x 4 lane rows)
+            __syncthreads();
+            double* red = &As[0][0];
+#pragma unroll
+            for (int y = 0; y < TN; ++y) red[((wm * 4 + lq) * BN) + wn * WN + y * 16 + lr] = bsum[y];
+            __syncthreads();
+            for (int j = tid; j < BN; j += 256) {
+                double sum = 0.0;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) sum += red[p * BN + j];
+                if (n0 + j < g.N) f.bpart[(size_t)ti * g.N + n0 + j] = sum;
+            }
+        }
+        return;
+    }
+
     // ---- fused gradient epilogue (TAG 2): T = (acc + ycoef y wv^T) .* h(r), sum Q .* k / var
     if (TAG == 2 && g.fuse_on) {
         // scaled inputs of this tile's rows / columns, staged in the (now idle) operand LDS:
@@ -435,6 +486,7 @@ static void launch_variant(bool akm, bool bkm, int tag, dim3 grid, hipStream_t s
     if (tag == 9 && akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, true, 9>), grid, dim3(256), 0, s, g);
     else if (tag == 1 && akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, true, 1>), grid, dim3(256), 0, s, g);
     else if (tag == 2 && !akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, true, 2>), grid, dim3(256), 0, s, g);
+    else if (tag == 3 && !akm && !bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, false, 3>), grid, dim3(256), 0, s, g);
     else if (akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, true, 0>), grid, dim3(256), 0, s, g);
     else if (akm && !bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, false, 0>), grid, dim3(256), 0, s, g);
     else if (!akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, true, 0>), grid, dim3(256), 0, s, g);
@@ -464,6 +516,13 @@ static int gemm_impl(Ctx* c, bool transA, bool transB, int M, int N, int K, doub
     g.dephase = c->gemm_dephase;
     g.stamps = nullptr;
     g.fuse_on = 0;
+    if (o.tag == 3) {
+        if (o.fusek == nullptr || splits != 1 || o.batch != 1 || o.tri) {
+            set_error("kernel-matrix epilogue needs an unsplit, unbatched, full-grid product");
+            return EDRGP_ERR_INVALID;
+        }
+        g.fusek = *o.fusek;
+    }
     if (o.fuse != nullptr && o.tag == 2) {
         if (splits != 1 || o.batch != 1 || alpha != 1.0 || beta != 0.0) {
             set_error("fused gradient epilogue needs an unsplit, unbatched alpha=1 beta=0 product");
