@@ -147,6 +147,7 @@ template <int BM, int BN, bool AKM, bool BKM, int TAG>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int TM = WM / 16, TN = WN / 16;
+    constexpr bool EARLY_STORE = (BM == 128);      // long MFMA phase: stage the next tile mid-phase
     typedef TileLoader<BM, AKM> LA;
     typedef TileLoader<BN, BKM> LB;
     __shared__ __attribute__((aligned(16))) double As[2][LA::SIZE];
@@ -289,11 +290,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 #pragma unroll
                     for (int y = 0; y < TN; ++y)
                         acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);
+                if (EARLY_STORE && kk == BK / 4 - 2) {
+                    // The next tile's registers go to the free LDS buffer in the MIDDLE of the
+                    // MFMA phase (their loads were issued two k-steps ago), so the write latency
+                    // hides under the remaining MFMAs and the tail of the iteration is the barrier only.
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) {
+                        la.store(As[buf ^ 1], tid);
+                        lb.store(Bs[buf ^ 1], tid);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             if (g.dephase == 3) __builtin_amdgcn_s_setprio(2);
             if (g.dephase == 4) __builtin_amdgcn_s_setprio(0);
             GEMM_STAMP(st_mfma)
-            if (more) {
+            if (!EARLY_STORE && more) {
                 la.store(As[buf ^ 1], tid);
                 lb.store(Bs[buf ^ 1], tid);
             }

@@ -11,7 +11,7 @@ h.set_kernel(["RBF"], [1.0], np.full((1, D), np.sqrt(D)), 0.01)
 prof = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 h.set_option("profile", prof)
 if len(sys.argv) > 2:
-    h.set_option("tri_tile", int(sys.argv[2]))
+    h.set_option("overlap", int(sys.argv[2]))
 h.sparse_lml_grad()
 ts = []
 for i in range(12):
