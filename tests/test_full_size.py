@@ -1,0 +1,104 @@
+"""Parity at BASELINE.json's full sizes through size-independent properties (the oracle
+needs minutes there): additivity of the row statistics over row blocks, chunking
+invariance, row-permutation invariance, central finite differences of the bound against
+the analytic gradients, and finite differences of the posterior mean against
+predict_gradient.  Configs: Cm (N=100k, M=2048, D=32, RBF) and C2 (N=100k, M=1024, D=16, RBF),
+C3's per-GPU shard shape with Matern-5/2 (N=125k, M=2048, D=32)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def synthetic(N, D, M, seed):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((N, D))
+    y = np.tanh(X @ (np.ones(D) / np.sqrt(D))) + 0.05 * rng.standard_normal(N)
+    y = (y - y.mean()) / y.std()
+    Z = X[rng.permutation(N)[:M]].copy()
+    return X, y, Z
+
+
+CONFIGS = [("Cm", 100000, 2048, 32, "RBF"), ("C2", 100000, 1024, 16, "RBF"), ("C3-shard", 125000, 2048, 32, "Matern52")]
+
+
+@pytest.mark.parametrize("name,N,M,D,kind", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_full_size_properties(hip, name, N, M, D, kind):
+    X, y, Z = synthetic(N, D, M, seed=4)
+    ls = np.full((1, D), np.sqrt(D))
+    hip.set_option("stats_mode", 1)           # Gram form: Phi and b are the exchanged statistics
+    try:
+        hip.set_data(X, y)
+        hip.set_inducing(Z)
+        hip.set_kernel([kind], [1.0], ls, 0.01)
+        lml, dvar, dlen, dnoise, dZ = hip.sparse_lml_grad()
+        assert np.isfinite(lml)
+        Phi = hip.get("PHI", (M, M))
+        b = hip.get("BVEC", (M,))
+        assert np.array_equal(Phi, Phi.T)
+
+        # (1) chunking invariance (ragged chunks)
+        hip.set_option("chunk_rows", 30000)
+        lml_c, dvar_c, dlen_c, dnoise_c, dZ_c = hip.sparse_lml_grad()
+        hip.set_option("chunk_rows", 131072)
+        # (different summation order of Phi, amplified by cond(Kmm) ~ 1e4: a few 1e-11 observed)
+        assert abs(lml_c - lml) <= 1e-9 * abs(lml)
+        assert abs(dvar_c[0] - dvar[0]) <= 1e-7 * abs(dvar[0])
+        assert np.abs(dZ_c - dZ).max() <= 1e-6 * np.abs(dZ).max()
+
+        # (2) finite differences of the bound (central, relative step 1e-3) vs analytic gradients
+        def bound(var=1.0, l=np.sqrt(D), noise=0.01, Zz=Z):
+            hip.set_inducing(Zz)
+            hip.set_kernel([kind], [var], np.full((1, D), l), noise)
+            return hip.sparse_lml()
+        for label, g, f in (("variance", dvar[0], lambda e: bound(var=1.0 * (1 + e))),
+                            ("lengthscale", dlen[0].sum() * np.sqrt(D), lambda e: bound(l=np.sqrt(D) * (1 + e))),
+                            ("noise", dnoise * 0.01, lambda e: bound(noise=0.01 * (1 + e)))):
+            # step 1e-3: the Gram-form bound carries ~1e-9 relative rounding noise at cond(Kmm) ~ 5e4
+            # (C2), which a 1e-5 step would amplify to 4e-5 of the derivative
+            e = 1e-3
+            fd = (f(e) - f(-e)) / (2 * e)              # d bound / d log(param)
+            assert abs(fd - g) <= 1e-4 * max(abs(g), abs(lml) * 1e-6), (label, fd, g)
+        # inducing inputs: directional derivative along a random direction (a single entry's
+        # difference quotient drowns in the 1e-11 relative rounding of a bound of magnitude 6e5)
+        V = np.random.default_rng(5).standard_normal(Z.shape)
+        t = 1e-4
+        fd = (bound(Zz=Z + t * V) - bound(Zz=Z - t * V)) / (2 * t)
+        an = float(np.sum(dZ * V))
+        assert abs(fd - an) <= 1e-3 * abs(an), (fd, an)
+
+        # (3) additivity of the row statistics over two row blocks + permutation invariance
+        hip.set_inducing(Z)
+        hip.set_kernel([kind], [1.0], ls, 0.01)
+        half = N // 2
+        hip.set_data(X[:half], y[:half])
+        hip.sparse_lml()
+        Phi1, b1 = hip.get("PHI", (M, M)), hip.get("BVEC", (M,))
+        hip.set_data(X[half:], y[half:])
+        hip.sparse_lml()
+        Phi2, b2 = hip.get("PHI", (M, M)), hip.get("BVEC", (M,))
+        assert np.abs(Phi1 + Phi2 - Phi).max() <= 1e-12 * np.abs(Phi).max()
+        assert np.abs(b1 + b2 - b).max() <= 1e-11 * np.abs(b).max()
+        perm = np.random.default_rng(0).permutation(N)
+        hip.set_data(X[perm], y[perm])
+        assert abs(hip.sparse_lml() - lml) <= 1e-9 * abs(lml)
+
+        # (4) posterior: mean-gradient at training rows vs finite differences of the mean
+        hip.set_data(X, y)
+        hip.sparse_posterior()
+        mean, jac = hip.predict_train()
+        assert np.isfinite(mean).all() and np.isfinite(jac).all()
+        resid = np.mean((mean - y) ** 2)
+        assert resid < 0.5                              # the GP explains the standardised signal
+        rows = np.array([0, 1, N // 3, N - 1])
+        for q in (0, D - 1):
+            h_ = 1e-5
+            Xp, Xm = X[rows].copy(), X[rows].copy()
+            Xp[:, q] += h_
+            Xm[:, q] -= h_
+            fdj = (hip.predict(Xp, False)[0] - hip.predict(Xm, False)[0]) / (2 * h_)
+            assert np.abs(fdj - jac[rows, q]).max() <= 1e-5 * max(1.0, np.abs(jac[rows]).max())
+        assert np.abs(hip.predict(X[rows], False)[0] - mean[rows]).max() <= 1e-10
+    finally:
+        hip.set_option("stats_mode", 0)
+        hip.set_option("chunk_rows", 131072)

@@ -144,3 +144,32 @@ def test_block_edr_zero_structure():
     edr.fit(X, y, max_iters=200)
     assert edr.components_.shape == (2, 6)
     assert np.all(edr.components_[0, 3:] == 0) and np.all(edr.components_[1, :3] == 0)
+
+
+def test_large_sparse_fit_end_to_end():
+    """The estimator API at a size GPy's CPU path would take minutes on: real L-BFGS-B fit
+    (hyper-parameters and inducing inputs), prediction quality, gradient direction."""
+    rng = np.random.default_rng(0)
+    N, D, M = 20000, 8, 256
+    X = rng.standard_normal((N, D))
+    w = np.zeros(D)
+    w[:2] = [0.8, -0.6]
+    y = np.tanh(X @ w) + 0.05 * rng.standard_normal(N)
+    np.random.seed(0)
+    est = SparseGaussianProcessRegressor(kernels="RBF", kernel_options={"ARD": True}, num_inducing=M)
+    est.fit(X, y, max_iters=40)
+    Xt = rng.standard_normal((2000, D))
+    yt = np.tanh(Xt @ w)
+    pred = est.predict(Xt)
+    assert pred.shape == (2000,)
+    assert np.mean((pred - yt) ** 2) < 0.02 * np.var(yt) + 1e-3
+    assert est.predict_variance(Xt[:10]).shape == (10, 1)
+    grad = est.predict_gradient(Xt[:500])
+    true_grad = (1 - np.tanh(Xt[:500] @ w) ** 2)[:, None] * w[None, :]
+    cos = np.sum(grad * true_grad, 1) / (np.linalg.norm(grad, axis=1) * np.linalg.norm(true_grad, axis=1) + 1e-12)
+    assert np.median(cos) > 0.95
+    ll = est.estimator_.log_likelihood()
+    assert ll.shape == (1, 1) and np.isfinite(ll[0, 0])
+    # ARD found the two active inputs: their lengthscales are the shortest
+    ls = est.estimator_.kern.parts[0].lengthscale
+    assert set(np.argsort(ls)[:2]) == {0, 1}
