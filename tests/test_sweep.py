@@ -1,0 +1,40 @@
+"""Config 4 (candidate-direction x length-scale sweep): every sweep entry equals the
+oracle's bound / mean-gradient on the projected data; rank sharding partitions the
+entries without overlap."""
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as go
+
+pytestmark = pytest.mark.gpu
+
+
+def test_projection_sweep_matches_oracle_and_shards(hip):
+    from edrgp_amd.sweep import length_scale_grid, projection_sweep
+    rng = np.random.default_rng(3)
+    N, D, M = 600, 6, 40
+    X = rng.standard_normal((N, D))
+    y = np.tanh(X[:, 0] - 0.5 * X[:, 1]) + 0.05 * rng.standard_normal(N)
+    y = (y - y.mean()) / y.std()
+    projections = [np.linalg.qr(rng.standard_normal((D, D - c)))[0] for c in range(3)]
+    Zrows = rng.permutation(N)[:M]
+    full = projection_sweep(X, y, Zrows, projections, n_scales=4, want_gradients=True, hip=hip)
+    assert len(full) == 12
+    for rec in full:
+        W = projections[rec["candidate"]]
+        Xp = X @ W
+        kern = go.make_kernel(["RBF"], Xp.shape[1], [dict(variance=1.0, lengthscale=rec["lengthscale"])])
+        inf = go.vardtc_inference(kern, Xp, Xp[Zrows], 0.01, y[:, None])
+        ref = inf["log_marginal"][0, 0]
+        assert abs(rec["bound"] - ref) <= 1e-9 * abs(ref)
+        jac = go.predictive_gradients_mean(kern, Xp, Xp[Zrows], inf["woodbury_vector"])[:, :, 0]
+        assert np.abs(rec["grad"] - jac).max() <= 1e-7 * max(1.0, np.abs(jac).max())
+        assert rec["grad_full"].shape == (N, D)
+        assert np.isclose(rec["lengthscale"], length_scale_grid(Xp.shape[1], 4)[rec["scale"]])
+    parts = [projection_sweep(X, y, Zrows, projections, n_scales=4, rank=r, world_size=2, hip=hip) for r in range(2)]
+    keys = [sorted((p["candidate"], p["scale"]) for p in part) for part in parts]
+    assert not set(keys[0]) & set(keys[1]) and len(keys[0]) + len(keys[1]) == 12
+    lookup = {(p["candidate"], p["scale"]): p["bound"] for p in full}
+    for part in parts:
+        for p in part:
+            assert p["bound"] == lookup[(p["candidate"], p["scale"])]
