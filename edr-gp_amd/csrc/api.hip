@@ -1160,8 +1160,10 @@ int edrgp_calib(edrgp_ctx* ctx, double* mfma_f64_tflops, double* hbm_copy_gbps) 
     if (getenv("EDRGP_CALIB_PATTERNS")) {
         double t[8] = {0};
         TRY(calib_mfma_patterns(c, t));
-        fprintf(stderr, "[calib] 2 waves/SIMD: 4x4 grid %.1f | AGPR acc %.1f | one A/B pair %.1f | +LDS frag reads %.1f | +global loads %.1f TF;"
-                        " 1 wave/SIMD: 4x4 grid %.1f | +LDS frag reads %.1f TF\n", t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
+        fprintf(stderr, "[calib] fp64 MFMA TFLOP/s, 2 waves/SIMD: registers only %.1f | AGPR acc %.1f | one A/B pair %.1f | "
+                        "+LDS fragment reads %.1f | +barrier/k-tile %.1f | +staging ds_write (no barrier) %.1f | "
+                        "+streaming global loads (no barrier) %.1f | full loop skeleton %.1f\n",
+                t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
     }
     if (mfma_f64_tflops) TRY(calib_mfma_f64(c, mfma_f64_tflops));
     if (hbm_copy_gbps) TRY(calib_hbm_copy(c, hbm_copy_gbps));

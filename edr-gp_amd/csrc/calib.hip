@@ -28,12 +28,17 @@ __global__ __launch_bounds__(256) void mfma_f64_rate_kernel(int iters, double* s
 // P=2: same with AGPR accumulators; P=3: 16 accumulators, one A/B pair.
 #define MFMA_V(acc, a, b) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
 #define MFMA_A(acc, a, b) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
-template <int P>
-__global__ __launch_bounds__(256, 2) void mfma_pattern_kernel(int iters, double* sink, const double* __restrict__ gsrc) {
-    __shared__ double lds[16][144];
+// Issue-pattern probes of the GEMM inner loop.  Bits of F add one ingredient each per
+// 64 MFMAs (= one k-tile): 1 = LDS fragment reads (8 per 16 MFMAs), 2 = workgroup barrier,
+// 4 = 8 ds_write_b128 (staging stores), 8 = 8 streaming global_load_dwordx4.
+// AG = 1: accumulators in AGPRs; ONE = 1: a single A/B pair.
+template <int F, int AG, int ONE>
+__global__ __launch_bounds__(256, 2) void mfma_pattern_kernel(int iters, double* sink, const double* __restrict__ gsrc,
+                                                             long long gstride) {
+    __shared__ __attribute__((aligned(16))) double lds[2][16][144];
     const int lane = threadIdx.x & 63;
     const int lr = lane & 15, lq = lane >> 4;
-    for (int i = threadIdx.x; i < 16 * 144; i += 256) lds[i / 144][i % 144] = 1.0 + 1e-6 * i;
+    for (int i = threadIdx.x; i < 2 * 16 * 144; i += 256) (&lds[0][0][0])[i] = 1.0 + 1e-6 * i;
     __syncthreads();
     double a[4], b[4];
 #pragma unroll
@@ -43,25 +48,39 @@ __global__ __launch_bounds__(256, 2) void mfma_pattern_kernel(int iters, double*
     for (int x = 0; x < 4; ++x)
 #pragma unroll
         for (int y = 0; y < 4; ++y) acc[x][y] = d4{0, 0, 0, 0};
-    const double* gp = gsrc + (size_t)(blockIdx.x % 64) * 4096 + lane;
-    for (int i = 0; i < iters; ++i) {
-        if (P == 4) {            // 8 LDS fragment reads per 16 MFMAs, as the GEMM inner loop does
-            const int kk = i & 3;
+    const char* gbase = reinterpret_cast<const char*>(gsrc) + (long long)blockIdx.x * gstride;
+    const unsigned goff = threadIdx.x * 16;
+    double2 st[8];
 #pragma unroll
-            for (int x = 0; x < 4; ++x) { a[x] = lds[kk * 4 + lq][x * 16 + lr]; b[x] = lds[kk * 4 + lq][64 + x * 16 + lr]; }
+    for (int v = 0; v < 8; ++v) st[v] = double2{1.0, 2.0};
+    for (int i = 0; i < iters; ++i) {            // one iteration = one k-tile = 64 MFMAs per wave
+        const int buf = i & 1;
+        if (F & 8) {
+#pragma unroll
+            for (int v = 0; v < 8; ++v) st[v] = *reinterpret_cast<const double2*>(gbase + goff + v * 4096);
+            gbase += 32768;
         }
-        if (P == 5) {            // 8 global loads (L2-resident) per 16 MFMAs
 #pragma unroll
-            for (int x = 0; x < 4; ++x) { a[x] = gp[((i & 7) * 8 + x) * 64]; b[x] = gp[((i & 7) * 8 + 4 + x) * 64]; }
-        }
+        for (int kk = 0; kk < 4; ++kk) {
+            if (F & 1) {
 #pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-            for (int y = 0; y < 4; ++y) {
-                if (P == 2) MFMA_A(acc[x][y], a[x], b[y]);
-                else if (P == 3) MFMA_V(acc[x][y], a[0], b[0]);
-                else MFMA_V(acc[x][y], a[x], b[y]);
+                for (int x = 0; x < 4; ++x) { a[x] = lds[buf][kk * 4 + lq][x * 16 + lr]; b[x] = lds[buf][kk * 4 + lq][64 + x * 16 + lr]; }
             }
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) {
+                    if (AG) MFMA_A(acc[x][y], a[x], b[y]);
+                    else if (ONE) MFMA_V(acc[x][y], a[0], b[0]);
+                    else MFMA_V(acc[x][y], a[x], b[y]);
+                }
+        }
+        if (F & 4) {
+#pragma unroll
+            for (int v = 0; v < 8; ++v)
+                *reinterpret_cast<double2*>(&lds[buf ^ 1][(v * 2 + (threadIdx.x >> 7)) & 15][(threadIdx.x & 63) * 2]) = st[v];
+        }
+        if (F & 2) __syncthreads();
     }
     asm volatile("s_nop 15\n\ts_nop 15");
     d4 s = {0, 0, 0, 0};
@@ -69,41 +88,46 @@ __global__ __launch_bounds__(256, 2) void mfma_pattern_kernel(int iters, double*
     for (int x = 0; x < 4; ++x)
 #pragma unroll
         for (int y = 0; y < 4; ++y) s += acc[x][y];
-    if (s[0] + s[1] + s[2] + s[3] == -1.0) sink[0] = s[0];
+    if (s[0] + s[1] + s[2] + s[3] + st[3].x == -1.0) sink[0] = s[0];
 }
 
-int calib_mfma_patterns(Ctx* c, double* tflops8) {
-    TRY(c->red.reserve(64));
-    DBuf g;
-    TRY(g.reserve((size_t)64 * 4096 * 2 * sizeof(double)));
-    HIP_TRY(hipMemsetAsync(g.p, 0, g.bytes, c->stream));
-    const int iters = 2500;
-    // P: 1 = 4x4 grid VGPR acc, 2 = AGPR acc, 3 = one A/B pair, 4 = + LDS fragment reads, 5 = + global loads,
-    //    6 = pattern 1 with ONE wave per SIMD, 7 = pattern 4 with one wave per SIMD
-    for (int P = 1; P <= 7; ++P) {
-        const int blocks = (P >= 6) ? c->num_cu : c->num_cu * 2;
-        hipEvent_t e0, e1;
-        HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
-        for (int rep = 0; rep < 2; ++rep) {
-            if (rep == 1) HIP_TRY(hipEventRecord(e0, c->stream));
-            const double* gs = g.d();
-            switch (P) {
-                case 1: case 6: hipLaunchKernelGGL(mfma_pattern_kernel<1>, dim3(blocks), dim3(256), 0, c->stream, iters, c->red.d(), gs); break;
-                case 2: hipLaunchKernelGGL(mfma_pattern_kernel<2>, dim3(blocks), dim3(256), 0, c->stream, iters, c->red.d(), gs); break;
-                case 3: hipLaunchKernelGGL(mfma_pattern_kernel<3>, dim3(blocks), dim3(256), 0, c->stream, iters, c->red.d(), gs); break;
-                case 4: case 7: hipLaunchKernelGGL(mfma_pattern_kernel<4>, dim3(blocks), dim3(256), 0, c->stream, iters, c->red.d(), gs); break;
-                default: hipLaunchKernelGGL(mfma_pattern_kernel<5>, dim3(blocks), dim3(256), 0, c->stream, iters, c->red.d(), gs); break;
-            }
-        }
-        HIP_TRY(hipEventRecord(e1, c->stream));
-        HIP_TRY(hipEventSynchronize(e1));
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        tflops8[P] = (double)blocks * 4.0 * iters * 16.0 * 2048.0 / (ms * 1e-3) * 1e-12;
+template <int F, int AG, int ONE>
+static int run_pattern(Ctx* c, int blocks, int iters, const double* gs, long long gstride, double* tf) {
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    for (int rep = 0; rep < 2; ++rep) {
+        if (rep == 1) HIP_TRY(hipEventRecord(e0, c->stream));
+        hipLaunchKernelGGL((mfma_pattern_kernel<F, AG, ONE>), dim3(blocks), dim3(256), 0, c->stream, iters, c->red.d(),
+                           gs, gstride);
     }
+    HIP_TRY(hipEventRecord(e1, c->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *tf = (double)blocks * 4.0 * iters * 64.0 * 2048.0 / (ms * 1e-3) * 1e-12;
+    return EDRGP_OK;
+}
+
+int calib_mfma_patterns(Ctx* c, double* t) {
+    TRY(c->red.reserve(64));
+    const int iters = 600, blocks = c->num_cu * 2;
+    // each workgroup streams its own 20 MB slice: (iters + 1) * 32 KiB
+    const long long gstride = (long long)(iters + 2) * 32768;
+    DBuf g;
+    TRY(g.reserve((size_t)blocks * gstride));
+    HIP_TRY(hipMemsetAsync(g.p, 0, g.bytes, c->stream));
+    const double* gs = g.d();
+    TRY((run_pattern<0, 0, 0>(c, blocks, iters, gs, gstride, &t[0])));      // 4x4 grid, registers only
+    TRY((run_pattern<0, 1, 0>(c, blocks, iters, gs, gstride, &t[1])));      // AGPR accumulators
+    TRY((run_pattern<0, 0, 1>(c, blocks, iters, gs, gstride, &t[2])));      // one A/B pair
+    TRY((run_pattern<1, 0, 0>(c, blocks, iters, gs, gstride, &t[3])));      // + LDS fragment reads
+    TRY((run_pattern<3, 0, 0>(c, blocks, iters, gs, gstride, &t[4])));      // + barrier per k-tile
+    TRY((run_pattern<5, 0, 0>(c, blocks, iters, gs, gstride, &t[5])));      // + staging stores (no barrier)
+    TRY((run_pattern<9, 0, 0>(c, blocks, iters, gs, gstride, &t[6])));      // + streaming global loads (no barrier)
+    TRY((run_pattern<15, 0, 0>(c, blocks, iters, gs, gstride, &t[7])));     // everything: the GEMM loop skeleton
     g.release();
     return EDRGP_OK;
 }

@@ -58,12 +58,12 @@ __global__ __launch_bounds__(64) void diag_block_kernel(double* __restrict__ Aba
     {
         const int cl = min(lane, jb - 1);
 #pragma unroll 1
-        for (int r0 = 0; r0 < NB; r0 += 8) {        // coalesced, clamped (branch-free), 8 rows in flight
-            double t[8];
+        for (int r0 = 0; r0 < NB; r0 += 32) {       // coalesced, clamped (branch-free), 32 rows in flight
+            double t[32];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = A[(size_t)min(r0 + u, jb - 1) * lda + cl];
+            for (int u = 0; u < 32; ++u) t[u] = A[(size_t)min(r0 + u, jb - 1) * lda + cl];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 32; ++u) {
                 const int r = r0 + u;
                 const bool in = (r < jb) && (lane < jb) && (lane <= r);
                 Lt[lane][r] = in ? t[u] : ((r == lane) ? 1.0 : 0.0);
@@ -106,8 +106,16 @@ __global__ __launch_bounds__(64) void diag_block_kernel(double* __restrict__ Aba
         __syncthreads();
         EDRGP_STAMP(2);
 #pragma unroll 1
-        for (int r = 0; r < jb; ++r)               // coalesced write-back, explicit zeros above the diagonal
-            if (lane < jb) A[(size_t)r * lda + lane] = (lane <= r) ? Lt[lane][r] : 0.0;
+        for (int r0 = 0; r0 < NB; r0 += 16) {      // coalesced write-back, explicit zeros above the diagonal
+            double t[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t[u] = Lt[lane][r0 + u];          // 16 LDS reads in flight
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int r = r0 + u;
+                if (r < jb && lane < jb) A[(size_t)r * lda + lane] = (lane <= r) ? t[u] : 0.0;
+            }
+        }
     } else {
         rdiag[lane] = 1.0 / Lt[lane][lane];
         __syncthreads();
