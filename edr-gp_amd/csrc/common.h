@@ -187,7 +187,9 @@ struct Ctx {
     DBuf red2, slabs2;                    // scratch used while launching on the side stream
     DBuf ks_x, ks_z, ks_xn, ks_zn, ks_x2, ks_xn2;   // scaled inputs and squared norms for the MFMA kernel build
     bool mfma_kbuild = true;
-    bool overlap = true;
+    int overlap = 3;                  // 0 none; 1 Kmm gradient term beside the gradient contraction;
+                                      // 2 also phase 1 beside the row pass (stretches the Phi kernel);
+                                      // 3 = 2 for bound-only evaluations, 1 for gradient evaluations
     bool fuse_grad = true;            // fused Q .* h epilogue of the gradient contraction (single-part kernels, D <= 32)
     int gemm_dephase = 3;             // see la_gemm.hip: 3 = staging / barrier phases at raised priority
     bool trace = false;

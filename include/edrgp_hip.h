@@ -82,7 +82,9 @@ int  edrgp_ctx_destroy(edrgp_ctx* ctx);
 int  edrgp_sync(edrgp_ctx* ctx);
 /* tunables: "chunk_rows", "syrk_splits", "profile" (0/1), "stats_mode" (0 auto,
  * 1 Gram form Phi = K_mn K_nm, 2 stable form via K_nm Lm^-T), "pivot_ratio_max",
- * "overlap" (0/1: run the O(M^3) phases on a side stream beside the row passes) */
+ * "overlap" (side-stream use: 0 none, 1 the Kmm gradient term beside the gradient contraction,
+ * 2 also the Kmm Cholesky beside the row pass, 3 (default) = 2 for bound-only and 1 for
+ * gradient evaluations) */
 int  edrgp_set_option(edrgp_ctx* ctx, const char* key, double value);
 
 /* Training data (already validated / normalised by the host: check_X_y at
