@@ -484,14 +484,24 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
             FuseT f;
             f.X = c->X.d() + (size_t)r0 * D; f.Z = c->Z.d(); f.y = c->y.d() + r0; f.wv = v_wv;
             f.invl = c->invl.d(); f.dvpart = c->red.d(); f.ycoef = beta; f.var = c->var[0]; f.D = D; f.kind = c->kind[0];
+            // the "ones" column of T^T [X | 1 | X.^2] comes out of the epilogue as column sums, so the
+            // trailing product is T^T [X | X.^2]: 2D = 64 columns = one column tile instead of two
+            const int tiles_m = (int)((rows + 127) / 128);
+            TRY(c->bpart.reserve((size_t)tiles_m * M * sizeof(double)));
+            TRY(c->g2.reserve(((size_t)M * 2 * D + M + 8) * sizeof(double)));
+            f.cspart = c->bpart.d();
+            double* G2 = c->g2.d();
+            double* csv = G2 + (size_t)M * 2 * D;
             GemmOpts o;
             o.tag = 2;
             o.force_tile = 128;
             o.fuse = &f;
             TRY(gemm(c, false, false, (int)rows, M, M, 1.0, c->Knm.d(), M, S2, M, 0.0, c->T.d(), M, o));
             TRY(sum_into(c, c->red.d(), ntiles, sc + SC_DVAR_NM));
-            TRY(gemm(c, true, false, M, Wd, (int)rows, 1.0, c->T.d(), M, c->Xt.d() + (size_t)r0 * Wd, Wd,
-                     ch > 0 ? 1.0 : 0.0, c->gt_nm.d(), Wd));
+            TRY(col_reduce(c, c->bpart.d(), tiles_m, M, csv));
+            TRY(gemm(c, true, false, M, 2 * D, (int)rows, 1.0, c->T.d(), M, c->Xq.d() + (size_t)r0 * 2 * D, 2 * D, 0.0, G2,
+                     2 * D));
+            TRY(assemble_gt(c, G2, csv, M, D, ch > 0 ? 1.0 : 0.0, c->gt_nm.d()));
             continue;
         }
         {
@@ -751,7 +761,7 @@ int edrgp_ctx_destroy(edrgp_ctx* ctx) {
     (void)hipStreamSynchronize(c->stream2);
     c->drain_events();
     if (c->comm) edrgp_comm_destroy(ctx);
-    DBuf* bufs[] = {&c->X, &c->y, &c->Z, &c->Xt, &c->Zt, &c->invl, &c->wv, &c->winv, &c->Knm, &c->W, &c->T, &c->slabs,
+    DBuf* bufs[] = {&c->X, &c->y, &c->Z, &c->Xt, &c->Zt, &c->Xq, &c->g2, &c->invl, &c->wv, &c->winv, &c->Knm, &c->W, &c->T, &c->slabs,
                     &c->bpart, &c->scal, &c->info, &c->gt_nm, &c->gt_mm, &c->panel, &c->trtri_ws, &c->dinv, &c->red};
     for (DBuf* b : bufs) b->release();
     for (auto& m : c->mats) m.release();
@@ -807,12 +817,14 @@ int edrgp_set_data(edrgp_ctx* ctx, const double* X, const double* y, int64_t N, 
     TRY(c->X.reserve((size_t)N * D * sizeof(double)));
     TRY(c->y.reserve((size_t)N * sizeof(double)));
     TRY(c->Xt.reserve((size_t)N * (2 * D + 1) * sizeof(double)));
+    TRY(c->Xq.reserve((size_t)N * 2 * D * sizeof(double)));
     TRY(c->scal.reserve(SC_COUNT * sizeof(double)));
     HIP_TRY(hipMemcpyAsync(c->X.d(), X, (size_t)N * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->y.d(), y, (size_t)N * sizeof(double), hipMemcpyHostToDevice, c->stream));
     c->N = N;
     c->D = D;
     TRY(build_xtilde(c, c->X.d(), N, D, c->Xt.d()));
+    TRY(build_xq(c, c->X.d(), N, D, c->Xq.d()));
     TRY(sum_sq(c, c->y.d(), N, c->scal.d() + SC_YY));
     double yy = 0.0;
     HIP_TRY(hipMemcpyAsync(&yy, c->scal.d() + SC_YY, sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1161,12 +1173,13 @@ int edrgp_dbg_mfma_layout(edrgp_ctx* ctx, const double* A16x4, const double* B4x
 int edrgp_calib(edrgp_ctx* ctx, double* mfma_f64_tflops, double* hbm_copy_gbps) {
     CTX(ctx);
     if (getenv("EDRGP_CALIB_PATTERNS")) {
-        double t[8] = {0};
+        double t[10] = {0};
         TRY(calib_mfma_patterns(c, t));
         fprintf(stderr, "[calib] fp64 MFMA TFLOP/s, 2 waves/SIMD: registers only %.1f | AGPR acc %.1f | one A/B pair %.1f | "
                         "+LDS fragment reads %.1f | +barrier/k-tile %.1f | +staging ds_write (no barrier) %.1f | "
-                        "+streaming global loads (no barrier) %.1f | full loop skeleton %.1f\n",
-                t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
+                        "+streaming global loads (no barrier) %.1f | full loop skeleton %.1f || 1 wave/SIMD 128x256 skeleton %.1f, "
+                        "with fragment prefetch %.1f\n",
+                t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9]);
     }
     if (mfma_f64_tflops) TRY(calib_mfma_f64(c, mfma_f64_tflops));
     if (hbm_copy_gbps) TRY(calib_hbm_copy(c, hbm_copy_gbps));

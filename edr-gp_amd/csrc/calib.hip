@@ -91,6 +91,78 @@ __global__ __launch_bounds__(256, 2) void mfma_pattern_kernel(int iters, double*
     if (s[0] + s[1] + s[2] + s[3] + st[3].x == -1.0) sink[0] = s[0];
 }
 
+// Big-tile skeleton: one wave per SIMD, 4x8 accumulator grid (64x128 per wave, 256 VGPRs of
+// accumulators), per k-tile 128 MFMAs, 12 fragment reads per k-step, 12 streaming loads,
+// 12 staging stores, one barrier.  PF = 1: fragments of k-step s+1 are read during step s.
+template <int PF>
+__global__ __launch_bounds__(256, 1) void mfma_bigtile_kernel(int iters, double* sink, const double* __restrict__ gsrc,
+                                                             long long gstride) {
+    __shared__ __attribute__((aligned(16))) double lds[2][16][400];
+    const int lane = threadIdx.x & 63;
+    const int lr = lane & 15, lq = lane >> 4;
+    for (int i = threadIdx.x; i < 2 * 16 * 400; i += 256) (&lds[0][0][0])[i] = 1.0 + 1e-6 * i;
+    __syncthreads();
+    d4 acc[4][8];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 8; ++y) acc[x][y] = d4{0, 0, 0, 0};
+    const char* gbase = reinterpret_cast<const char*>(gsrc) + (long long)blockIdx.x * gstride;
+    const unsigned goff = threadIdx.x * 16;
+    double2 st[12];
+#pragma unroll
+    for (int v = 0; v < 12; ++v) st[v] = double2{1.0, 2.0};
+    double a[2][4], b[2][8];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) a[0][x] = lds[0][lq][x * 16 + lr];
+#pragma unroll
+    for (int y = 0; y < 8; ++y) b[0][y] = lds[0][lq][128 + y * 16 + lr];
+    for (int i = 0; i < iters; ++i) {
+        const int buf = i & 1;
+#pragma unroll
+        for (int v = 0; v < 12; ++v) st[v] = *reinterpret_cast<const double2*>(gbase + goff + v * 4096);
+        gbase += 49152;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int cur = PF ? (kk & 1) : 0, nxt = PF ? ((kk + 1) & 1) : 0;
+            if (!PF) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) a[0][x] = lds[buf][kk * 4 + lq][x * 16 + lr];
+#pragma unroll
+                for (int y = 0; y < 8; ++y) b[0][y] = lds[buf][kk * 4 + lq][128 + y * 16 + lr];
+            } else if (kk < 3) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) a[nxt][x] = lds[buf][(kk + 1) * 4 + lq][x * 16 + lr];
+#pragma unroll
+                for (int y = 0; y < 8; ++y) b[nxt][y] = lds[buf][(kk + 1) * 4 + lq][128 + y * 16 + lr];
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 8; ++y) MFMA_V(acc[x][y], a[cur][x], b[cur][y]);
+            if (kk == 1) {
+#pragma unroll
+                for (int v = 0; v < 12; ++v)
+                    *reinterpret_cast<double2*>(&lds[buf ^ 1][(v + (threadIdx.x >> 7)) & 15][(threadIdx.x & 127) * 2]) = st[v];
+            }
+        }
+        __syncthreads();
+        if (PF) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) a[0][x] = lds[buf ^ 1][lq][x * 16 + lr];
+#pragma unroll
+            for (int y = 0; y < 8; ++y) b[0][y] = lds[buf ^ 1][lq][128 + y * 16 + lr];
+        }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15");
+    d4 s = {0, 0, 0, 0};
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 8; ++y) s += acc[x][y];
+    if (s[0] + s[1] + s[2] + s[3] + st[3].x == -1.0) sink[0] = s[0];
+}
+
 template <int F, int AG, int ONE>
 static int run_pattern(Ctx* c, int blocks, int iters, const double* gs, long long gstride, double* tf) {
     hipEvent_t e0, e1;
@@ -128,6 +200,24 @@ int calib_mfma_patterns(Ctx* c, double* t) {
     TRY((run_pattern<5, 0, 0>(c, blocks, iters, gs, gstride, &t[5])));      // + staging stores (no barrier)
     TRY((run_pattern<9, 0, 0>(c, blocks, iters, gs, gstride, &t[6])));      // + streaming global loads (no barrier)
     TRY((run_pattern<15, 0, 0>(c, blocks, iters, gs, gstride, &t[7])));     // everything: the GEMM loop skeleton
+    for (int pf = 0; pf < 2; ++pf) {                                          // big-tile skeleton, 1 wave per SIMD
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        const int it2 = iters / 2;
+        for (int rep = 0; rep < 2; ++rep) {
+            if (rep == 1) HIP_TRY(hipEventRecord(e0, c->stream));
+            if (pf) hipLaunchKernelGGL((mfma_bigtile_kernel<1>), dim3(c->num_cu), dim3(256), 0, c->stream, it2, c->red.d(), gs, gstride * 2);
+            else hipLaunchKernelGGL((mfma_bigtile_kernel<0>), dim3(c->num_cu), dim3(256), 0, c->stream, it2, c->red.d(), gs, gstride * 2);
+        }
+        HIP_TRY(hipEventRecord(e1, c->stream));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        t[8 + pf] = (double)c->num_cu * 4.0 * it2 * 128.0 * 2048.0 / (ms * 1e-3) * 1e-12;
+    }
     g.release();
     return EDRGP_OK;
 }

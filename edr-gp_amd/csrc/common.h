@@ -74,6 +74,7 @@ struct FuseT {
     const double* wv;       // M
     const double* invl;     // D
     double* dvpart;         // one partial per workgroup
+    double* cspart;         // tiles_m x M partial column sums of T (or null)
     double ycoef, var;
     int D, kind;
 };
@@ -166,6 +167,8 @@ int grad_elementwise(Ctx* c, const KSpec& ks, int part, const double* X, const d
                      double* T, int ldt, double* dvar_accum /* device scalar, += */);
 // Xt = [X | 1 | X.*X]  (rows x (2D+1))
 int build_xtilde(Ctx* c, const double* X, int64_t rows, int D, double* Xt);
+int build_xq(Ctx* c, const double* X, int64_t rows, int D, double* Xq);               // [X | X.^2]
+int assemble_gt(Ctx* c, const double* G2, const double* cs, int M, int D, double beta_acc, double* Gt);
 int sum_into(Ctx* c, const double* part, int n, double* accum);   // accum[0] += sum(part), fixed order
 int rowdot(Ctx* c, const double* A, const double* B, int64_t rows, int cols, int ld, double* out);
 // posterior mean / latent variance / mean Jacobian for one device-resident row chunk
@@ -199,7 +202,7 @@ struct Ctx {
     int64_t N = 0;
     int D = 0;
     int M = 0;
-    DBuf X, y, Z, Xt, Zt;             // Xt = [X|1|X.^2], Zt likewise for Z
+    DBuf X, y, Z, Xt, Zt, Xq;         // Xt = [X|1|X.^2], Zt likewise for Z, Xq = [X|X.^2]
     bool have_data = false, have_Z = false, have_kernel = false;
     double yy_local = 0.0;
 
@@ -228,6 +231,7 @@ struct Ctx {
     // workspace
     DBuf Knm, W, T;                   // chunk x M
     DBuf mats[16];                    // M x M (or N x N dense) matrices
+    DBuf g2;                          // T^T [X | X.^2] and column sums of T (fused gradient path)
     DBuf slabs, bpart, scal, info, gt_nm, gt_mm, tmpvec[6], panel, trtri_ws, dinv, red;
     std::vector<double> host_scal;
 

@@ -333,6 +333,45 @@ __global__ void xtilde_kernel(const double* __restrict__ X, int64_t rows, int D,
     }
 }
 
+// Xq[n] = [x_n | x_n .* x_n]  (rows x 2D)
+__global__ void xq_kernel(const double* __restrict__ X, int64_t rows, int D, double* __restrict__ Xq) {
+    const int W = 2 * D;
+    const int64_t total = rows * W;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t n = i / W;
+        const int q = (int)(i - n * W);
+        const double x = X[n * D + (q < D ? q : q - D)];
+        Xq[i] = (q < D) ? x : x * x;
+    }
+}
+
+int build_xq(Ctx* c, const double* X, int64_t rows, int D, double* Xq) {
+    const int64_t total = rows * 2 * D;
+    const int nb = (int)std::min<int64_t>(4096, (total + 255) / 256);
+    hipLaunchKernelGGL(xq_kernel, dim3(std::max(nb, 1)), dim3(256), 0, c->stream, X, rows, D, Xq);
+    HIP_TRY(hipGetLastError());
+    return EDRGP_OK;
+}
+
+// Gt[m] = [G2[m][0:D] | cs[m] | G2[m][D:2D]]  (+= when beta_acc == 1)
+__global__ void assemble_gt_kernel(const double* __restrict__ G2, const double* __restrict__ cs, int M, int D,
+                                   double beta_acc, double* __restrict__ Gt) {
+    const int W = 2 * D + 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * W) return;
+    const int m = i / W, q = i - m * W;
+    const double v = (q < D) ? G2[(size_t)m * 2 * D + q] : (q == D ? cs[m] : G2[(size_t)m * 2 * D + q - 1]);
+    Gt[i] = (beta_acc != 0.0) ? Gt[i] + v : v;
+}
+
+int assemble_gt(Ctx* c, const double* G2, const double* cs, int M, int D, double beta_acc, double* Gt) {
+    const int total = M * (2 * D + 1);
+    hipLaunchKernelGGL(assemble_gt_kernel, dim3((total + 255) / 256), dim3(256), 0, c->stream, G2, cs, M, D, beta_acc, Gt);
+    HIP_TRY(hipGetLastError());
+    return EDRGP_OK;
+}
+
 int build_xtilde(Ctx* c, const double* X, int64_t rows, int D, double* Xt) {
     const int64_t total = rows * (2 * D + 1);
     const int nb = (int)std::min<int64_t>(4096, (total + 255) / 256);

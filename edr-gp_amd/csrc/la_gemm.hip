@@ -402,6 +402,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
             wvc[y] = (col < g.N) ? f.wv[col] : 0.0;
         }
         double dv = 0.0;
+        double csum[TN];
+#pragma unroll
+        for (int y = 0; y < TN; ++y) csum[y] = 0.0;
 #pragma unroll
         for (int x = 0; x < TM; ++x) {
             double r2[TN][4];
@@ -435,9 +438,26 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                         double Kv, hv;
                         edrgp_kfun(f.kind, f.var, r2[y][r], Kv, hv);
                         dv = fma(Q, Kv, dv);
-                        C[(size_t)row * g.ldc + col] = (r2[y][r] == 0.0) ? 0.0 : Q * hv;
+                        const double tval = (r2[y][r] == 0.0) ? 0.0 : Q * hv;
+                        C[(size_t)row * g.ldc + col] = tval;
+                        csum[y] += tval;
                     }
                 }
+            }
+        }
+        if (f.cspart != nullptr) {
+            // column sums of T over the tile's rows (the "ones" column of T^T [X | 1 | X.^2]):
+            // 8 partials per column (2 row-waves x 4 lane rows), fixed order
+            __syncthreads();
+            double* redc = &Bs[0][0];
+#pragma unroll
+            for (int y = 0; y < TN; ++y) redc[((wm * 4 + lq) * BN) + wn * WN + y * 16 + lr] = csum[y];
+            __syncthreads();
+            for (int j = tid; j < BN; j += 256) {
+                double sum = 0.0;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) sum += redc[p * BN + j];
+                if (n0 + j < g.N) f.cspart[(size_t)ti * g.N + n0 + j] = sum;
             }
         }
         // fixed-order workgroup reduction of the d/dvariance partial

@@ -54,14 +54,24 @@ __global__ __launch_bounds__(256) void gemv_t_part_kernel(int M, int N, const do
                                            (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-// out[j] = alpha * sum_p part[p][j]
-__global__ void col_reduce_kernel(const double* __restrict__ part, int nparts, int n, double alpha,
-                                  double* __restrict__ out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
+// out[j] = alpha * sum_p part[p][j].  64 columns x 16 row groups per workgroup: group g adds
+// rows g, g+16, ... in order, then the 16 group sums are added in order (fixed summation order).
+__global__ __launch_bounds__(1024) void col_reduce_kernel(const double* __restrict__ part, int nparts, int n,
+                                                          double alpha, double* __restrict__ out) {
+    __shared__ double red[16][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
     double s = 0.0;
-    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * n + j];
-    out[j] = alpha * s;
+    if (j < n)
+        for (int p = grp; p < nparts; p += 16) s += part[(size_t)p * n + j];
+    red[grp][lane] = s;
+    __syncthreads();
+    if (grp == 0 && j < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][lane];
+        out[j] = alpha * t;
+    }
 }
 
 int gemv_n(Ctx* c, int M, int N, double alpha, const double* A, int lda, const double* x, double* y) {
@@ -76,14 +86,14 @@ int gemv_t(Ctx* c, int M, int N, double alpha, const double* A, int lda, const d
     TRY(c->red.reserve((size_t)nchunk * N * sizeof(double)));
     hipLaunchKernelGGL(gemv_t_part_kernel, dim3((N + 63) / 64, nchunk), dim3(256), 0, c->stream, M, N, A, lda,
                        x, c->red.d());
-    hipLaunchKernelGGL(col_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->red.d(), nchunk, N,
+    hipLaunchKernelGGL(col_reduce_kernel, dim3((N + 63) / 64), dim3(1024), 0, c->stream, c->red.d(), nchunk, N,
                        alpha, y);
     HIP_TRY(hipGetLastError());
     return EDRGP_OK;
 }
 
 int col_reduce(Ctx* c, const double* part, int nparts, int n, double* out) {
-    hipLaunchKernelGGL(col_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, part, nparts, n, 1.0,
+    hipLaunchKernelGGL(col_reduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, c->stream, part, nparts, n, 1.0,
                        out);
     HIP_TRY(hipGetLastError());
     return EDRGP_OK;
