@@ -36,6 +36,7 @@ class NotPositiveDefiniteError(EdrgpError, np.linalg.LinAlgError):
 
 
 _c_double_p = ctypes.POINTER(ctypes.c_double)
+_c_float_p = ctypes.POINTER(ctypes.c_float)
 _c_int_p = ctypes.POINTER(ctypes.c_int)
 _c_i64_p = ctypes.POINTER(ctypes.c_int64)
 _ctx_p = ctypes.c_void_p
@@ -69,6 +70,9 @@ PROTOTYPES = {
     "edrgp_dbg_gemm": [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                        ctypes.c_double, _c_double_p, ctypes.c_int, _c_double_p, ctypes.c_int,
                        ctypes.c_double, _c_double_p, ctypes.c_int],
+    "edrgp_dbg_gemm32": [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                         _c_float_p, ctypes.c_int, _c_float_p, ctypes.c_int, _c_float_p, ctypes.c_int],
+    "edrgp_dbg_syrk32": [_ctx_p, _c_float_p, ctypes.c_int64, ctypes.c_int, _c_double_p],
     "edrgp_dbg_potrf": [_ctx_p, _c_double_p, ctypes.c_int, _c_int_p],
     "edrgp_dbg_diag_stamps": [_ctx_p, _c_double_p, ctypes.c_int, _c_double_p],
     "edrgp_dbg_trtri": [_ctx_p, _c_double_p, _c_double_p, ctypes.c_int],

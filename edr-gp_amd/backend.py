@@ -173,6 +173,25 @@ class HipGP:
                                        A.shape[1], dptr(B), B.shape[1], float(beta), dptr(out), N))
         return out
 
+    def dbg_gemm32(self, A, B, transA=False, transB=False):
+        A = np.ascontiguousarray(A, dtype=np.float32)
+        B = np.ascontiguousarray(B, dtype=np.float32)
+        M = A.shape[1] if transA else A.shape[0]
+        K = A.shape[0] if transA else A.shape[1]
+        N = B.shape[0] if transB else B.shape[1]
+        out = np.zeros((M, N), dtype=np.float32)
+        fp = ctypes.POINTER(ctypes.c_float)
+        check(self._lib.edrgp_dbg_gemm32(self._ctx, int(transA), int(transB), M, N, K, A.ctypes.data_as(fp),
+                                         A.shape[1], B.ctypes.data_as(fp), B.shape[1], out.ctypes.data_as(fp), N))
+        return out
+
+    def dbg_syrk32(self, K):
+        K = np.ascontiguousarray(K, dtype=np.float32)
+        out = np.empty((K.shape[1], K.shape[1]))
+        check(self._lib.edrgp_dbg_syrk32(self._ctx, K.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), K.shape[0],
+                                         K.shape[1], dptr(out)))
+        return out
+
     def dbg_potrf(self, A):
         L = as_f64(A).copy()
         info = ctypes.c_int(0)

@@ -108,6 +108,7 @@ enum {  // device scalar slots (c->scal)
     SC_DVAR_MM = 10,         // + part (4)
     SC_YALPHA = 14, SC_SUMLOGL, SC_ALPHASQ, SC_TRKYI,
     SC_DIAGMIN = 18, SC_DIAGMAX = 19,
+    SC_LBDIAGMIN = 20, SC_LBDIAGMAX = 21, SC_PHIFROB = 22,
     SC_COUNT = 32
 };
 
@@ -301,7 +302,37 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
     // ---- phase 2: row statistics.  gram: Phi = K^T K, b = K^T y.
     //      stable: Phi := (K Li^T)^T (K Li^T), b := (K Li^T)^T y  (= Li b)
     bool k_resident = false;
+    // precision 32 asks for the fp32 row pass; it is used while the Gram form is safe in fp32
+    // (error ~ eps32 cond(Kmm), judged by the pivot-ratio proxy after phase 1), otherwise this
+    // evaluation falls back to the fp64 row pass (last_mode: 1 gram fp64, 2 stable fp64, 3 gram fp32)
+    //   Phi in fp32 (f32): fast attempt, kept only if the a-posteriori guard below accepts it; a rejected
+    //     attempt is remembered (phi32_bad) until the data, Z or the precision change.
+    //   gradient contraction in fp32 (g32): always -- its rounding reaches the gradients only, never
+    //     the positive definiteness of I + A.
+    const bool want32 = (c->precision == 32) && (np == 1);
+    const bool g32 = want32 && need_grad && D <= 64 && M >= 128 && std::min<int64_t>(chunk, N) >= 128;
+    bool f32 = want32 && !c->phi32_bad;
+    bool k32_resident = false;
     auto phase2 = [&](bool stable) -> int {
+        if (f32) {
+            // fp32 row pass: K_nm stored and multiplied in fp32, Phi / b accumulated into fp64
+            TRY(c->Knm32.reserve((size_t)chunk * M * sizeof(float)));
+            float* K32 = static_cast<float*>(c->Knm32.p);
+            for (int64_t ch = 0; ch < nchunks; ++ch) {
+                const int64_t r0 = ch * chunk;
+                const int64_t rows = std::min<int64_t>(chunk, N - r0);
+                double* btarget = (ch == 0) ? bvec : v_tmp;
+                {
+                    ProfScope ps(c, EDRGP_PROF_KBUILD);
+                    TRY(kernel_matrix32(c, ks, c->X.d() + (size_t)r0 * D, rows, c->Z.d(), M, K32, c->y.d() + r0, btarget));
+                }
+                if (ch > 0) TRY(vec_axpy(c, M, 1.0, v_tmp, bvec));
+                TRY(syrk32_tn(c, K32, rows, M, M, Phi, M, ch > 0));
+            }
+            k32_resident = (nchunks == 1);
+            if (c->comm) TRY(allreduce_sum(c, Phi, (size_t)M * M + M));
+            return EDRGP_OK;
+        }
         if (stable) TRY(c->W.reserve((size_t)chunk * M * sizeof(double)));
         for (int64_t ch = 0; ch < nchunks; ++ch) {
             const int64_t r0 = ch * chunk;
@@ -340,6 +371,7 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
     // keep the row pass alone on the GPU and use the side stream for the Kmm gradient term only
     const bool want_p1 = (c->overlap == 2) || (c->overlap == 3 && !need_grad);
     const bool optimistic = want_p1 && (c->stats_mode == 1 || (c->stats_mode == 0 && c->last_mode != 2));
+    const bool ran32 = f32;
     if (optimistic) {
         TRY(phase2(false));
         {
@@ -352,14 +384,19 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
         TRY(phase1());
     }
     const double pr = h_sc[SC_DIAGMAX] / h_sc[SC_DIAGMIN];
-    const bool stable = (c->stats_mode == 2) || (c->stats_mode == 0 && pr * pr > c->pivot_ratio_max);
-    c->last_mode = stable ? 2 : 1;
+    const double dmin_lm = h_sc[SC_DIAGMIN];
+    f32 = want32 && !c->phi32_bad && (pr * pr <= c->f32_ratio_max);
+    const bool stable64 = (c->stats_mode == 2) || (c->stats_mode == 0 && pr * pr > c->pivot_ratio_max);
+    bool stable = !f32 && stable64;
+    c->last_mode = f32 ? 3 : (stable ? 2 : 1);
     tr.mark("phase1 (+queued phase2)");
-    if (!optimistic || stable) TRY(phase2(stable));
+    if (!optimistic || stable || f32 != ran32) TRY(phase2(stable));
     tr.mark("phase2 queued");
 
     // ---- phase 3: A, B = I + A (jitchol ladder), LB^-1, the M-vectors and scalars
-    for (int lvl = -1;;) {
+    // no_jitter: return EDRGP_ERR_NOT_PD at the first failed factorisation instead of climbing the ladder
+    auto phase3 = [&](bool no_jitter) -> int {
+      for (int lvl = -1;;) {
         ProfScope ps(c, EDRGP_PROF_SMALL);
         HIP_TRY(hipMemsetAsync(sc, 0, SC_COUNT * sizeof(double), c->stream));
         if (stable) {
@@ -384,11 +421,46 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
         TRY(sum_sq(c, v_c, M, sc + SC_DATAFIT));
         TRY(sum_sq(c, v_u, M, sc + SC_USQ));
         TRY(frob_sq(c, LBi, M, M, sc + SC_LBIFROB));
+        if (f32) {
+            TRY(diag_minmax(c, LB, M, M, sc + SC_LBDIAGMIN));
+            TRY(frob_sq(c, Phi, M, M, sc + SC_PHIFROB));
+        }
         HIP_TRY(hipMemcpyAsync(h_sc, sc, sizeof(h_sc), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(h_info, info, sizeof(h_info), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (h_info[1] == 0) break;
+        if (no_jitter) { set_error("I + A not positive definite"); return EDRGP_ERR_NOT_PD; }
         if (++lvl > 4) { set_error("I + A not positive definite, even with jitter"); return EDRGP_ERR_NOT_PD; }
+      }
+      return EDRGP_OK;
+    };
+    {
+        int st3 = phase3(f32);
+        if (f32) {
+            // a-posteriori guard of the fp32 Gram form: the rounding error of Phi (relative gamma32 per
+            // entry, ||dPhi||_2 ~ 2 gamma32 ||Phi||_F / sqrt(M)) reaches A = beta Li Phi Li^T amplified by
+            // ||Li||_2^2 ~ 1 / min diag(Lm)^2 and must stay small against lambda_min(I + A) ~ min diag(LB)^2
+            bool bad = (st3 == EDRGP_ERR_NOT_PD);
+            if (st3 != EDRGP_OK && !bad) return st3;
+            if (!bad) {
+                const double gamma32 = 3e-7;
+                const double dphi = 2.0 * gamma32 * std::sqrt(h_sc[SC_PHIFROB] / M);
+                const double dlb = h_sc[SC_LBDIAGMIN];
+                const double rho = beta * dphi / (dmin_lm * dmin_lm * dlb * dlb);
+                c->f32_rho = rho;
+                bad = !(rho <= c->f32_guard);
+            }
+            if (bad) {          // this evaluation (and the following ones) take Phi from the fp64 row pass
+                f32 = false;
+                c->phi32_bad = true;
+                stable = stable64;
+                c->last_mode = stable ? 2 : 1;
+                TRY(phase2(stable));
+                TRY(phase3(false));
+            }
+        } else if (st3 != EDRGP_OK) {
+            return st3;
+        }
     }
     c->drain_events();
     tr.mark("phase3 synced");
@@ -463,10 +535,44 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
         if (st == EDRGP_OK) st = side.mark_done();
         if (st != EDRGP_OK) return st;
     }
-    TRY(c->W.reserve((size_t)chunk * M * sizeof(double)));
-    TRY(c->T.reserve((size_t)chunk * M * sizeof(double)));
     TRY(c->gt_nm.reserve((size_t)np * M * Wd * sizeof(double)));
-    for (int64_t ch = 0; ch < nchunks; ++ch) {
+    if (g32) {
+        // fp32 gradient row pass: T = (K32 S2 + beta y wv^T) .* h(r) out of the contraction's epilogue,
+        // then T^T [X | X.^2]; partial sums and the M x 2D result are fp64
+        TRY(c->Knm32.reserve((size_t)chunk * M * sizeof(float)));
+        TRY(c->T32.reserve((size_t)chunk * M * sizeof(float)));
+        TRY(c->S2f.reserve((size_t)M * M * sizeof(float)));
+        TRY(c->g2.reserve(((size_t)M * 2 * D + M + 8) * sizeof(double)));
+        if (!c->xq32_valid) {
+            TRY(c->Xq32.reserve((size_t)N * 2 * D * sizeof(float)));
+            TRY(build_xq32(c, c->X.d(), N, D, static_cast<float*>(c->Xq32.p)));
+            c->xq32_valid = true;
+        }
+        float* K32 = static_cast<float*>(c->Knm32.p);
+        float* T32 = static_cast<float*>(c->T32.p);
+        float* S2f = static_cast<float*>(c->S2f.p);
+        const float* Xq32 = static_cast<const float*>(c->Xq32.p);
+        double* G2 = c->g2.d();
+        double* csv = G2 + (size_t)M * 2 * D;
+        TRY(to_f32(c, S2, (size_t)M * M, S2f));
+        for (int64_t ch = 0; ch < nchunks; ++ch) {
+            const int64_t r0 = ch * chunk;
+            const int64_t rows = std::min<int64_t>(chunk, N - r0);
+            if (!k32_resident) {
+                ProfScope ps(c, EDRGP_PROF_KBUILD);
+                TRY(kernel_matrix32(c, ks, c->X.d() + (size_t)r0 * D, rows, c->Z.d(), M, K32, nullptr, nullptr));
+            }
+            ProfScope ps(c, EDRGP_PROF_GRADGEMM);
+            TRY(grad_contract32(c, ks, K32, rows, M, S2f, c->y.d() + r0, v_wv, beta, T32, sc + SC_DVAR_NM, csv));
+            TRY(gemm32_tn_rows(c, M, 2 * D, rows, T32, M, Xq32 + (size_t)r0 * 2 * D, 2 * D, G2, 2 * D, false));
+            TRY(assemble_gt(c, G2, csv, M, D, ch > 0 ? 1.0 : 0.0, c->gt_nm.d()));
+        }
+    }
+    if (!g32) {
+        TRY(c->W.reserve((size_t)chunk * M * sizeof(double)));
+        TRY(c->T.reserve((size_t)chunk * M * sizeof(double)));
+    }
+    for (int64_t ch = 0; !g32 && ch < nchunks; ++ch) {
         const int64_t r0 = ch * chunk;
         const int64_t rows = std::min<int64_t>(chunk, N - r0);
         if (!k_resident) {
@@ -761,7 +867,8 @@ int edrgp_ctx_destroy(edrgp_ctx* ctx) {
     (void)hipStreamSynchronize(c->stream2);
     c->drain_events();
     if (c->comm) edrgp_comm_destroy(ctx);
-    DBuf* bufs[] = {&c->X, &c->y, &c->Z, &c->Xt, &c->Zt, &c->Xq, &c->g2, &c->invl, &c->wv, &c->winv, &c->Knm, &c->W, &c->T, &c->slabs,
+    DBuf* bufs[] = {&c->X, &c->y, &c->Z, &c->Xt, &c->Zt, &c->Xq, &c->g2, &c->Knm32, &c->T32, &c->S2f, &c->Xq32,
+                    &c->ks32_x, &c->ks32_z, &c->ks32_xn, &c->ks32_zn, &c->invl, &c->wv, &c->winv, &c->Knm, &c->W, &c->T, &c->slabs,
                     &c->bpart, &c->scal, &c->info, &c->gt_nm, &c->gt_mm, &c->panel, &c->trtri_ws, &c->dinv, &c->red};
     for (DBuf* b : bufs) b->release();
     for (auto& m : c->mats) m.release();
@@ -804,6 +911,16 @@ int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
     else if (!std::strcmp(key, "fuse_grad")) c->fuse_grad = (value != 0.0);
     else if (!std::strcmp(key, "tri_tile")) g_tri_tile = (int)value;
     else if (!std::strcmp(key, "mfma_kbuild")) c->mfma_kbuild = (value != 0.0);
+    else if (!std::strcmp(key, "f32_ratio_max")) c->f32_ratio_max = value;
+    else if (!std::strcmp(key, "f32_guard")) c->f32_guard = value;
+    else if (!std::strcmp(key, "precision")) {
+        // 64 (default): fp64 throughout.  32: the N-proportional row pass in fp32 (la_gemm32.hip)
+        if ((int)value != 32 && (int)value != 64) { set_error("precision must be 32 or 64"); return EDRGP_ERR_INVALID; }
+        c->precision = (int)value;
+        c->have_post = false;
+        c->last_mode = 0;
+        c->phi32_bad = false;
+    }
     else { set_error("unknown option %s", key); return EDRGP_ERR_INVALID; }
     return EDRGP_OK;
 }
@@ -823,6 +940,8 @@ int edrgp_set_data(edrgp_ctx* ctx, const double* X, const double* y, int64_t N, 
     HIP_TRY(hipMemcpyAsync(c->y.d(), y, (size_t)N * sizeof(double), hipMemcpyHostToDevice, c->stream));
     c->N = N;
     c->D = D;
+    c->xq32_valid = false;
+    c->phi32_bad = false;
     TRY(build_xtilde(c, c->X.d(), N, D, c->Xt.d()));
     TRY(build_xq(c, c->X.d(), N, D, c->Xq.d()));
     TRY(sum_sq(c, c->y.d(), N, c->scal.d() + SC_YY));
@@ -844,6 +963,7 @@ int edrgp_set_inducing(edrgp_ctx* ctx, const double* Z, int M) {
     HIP_TRY(hipMemcpyAsync(c->Z.d(), Z, (size_t)M * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
     TRY(build_xtilde(c, c->Z.d(), M, D, c->Zt.d()));
     HIP_TRY(hipStreamSynchronize(c->stream));   // Z is a borrowed host pointer
+    if (c->M != M) c->phi32_bad = false;
     c->M = M;
     c->have_Z = true;
     if (!c->post_dense) c->have_post = false;
@@ -980,12 +1100,26 @@ int edrgp_get(edrgp_ctx* ctx, int which, double* buf, int64_t cap) {
         case EDRGP_GET_A: src = c->mats[MAT_A].d(); n = M * M; break;
         case EDRGP_GET_WV: src = c->wv.d(); n = (size_t)c->P; break;
         case EDRGP_GET_WINV: src = c->winv.d(); n = (size_t)c->P * c->P; break;
-        case EDRGP_GET_KNM: src = c->Knm.d(); n = (size_t)std::min<int64_t>(c->N, c->chunk_rows) * M; break;
+        case EDRGP_GET_KNM:
+            n = (size_t)std::min<int64_t>(c->N, c->chunk_rows) * M;
+            if (c->last_mode == 3) {          // fp32 row pass: widen the resident chunk
+                if ((int64_t)n > cap) { set_error("edrgp_get: buffer too small"); return EDRGP_ERR_INVALID; }
+                std::vector<float> tmp(n);
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                HIP_TRY(hipMemcpy(tmp.data(), c->Knm32.p, n * sizeof(float), hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < n; ++i) buf[i] = (double)tmp[i];
+                return EDRGP_OK;
+            }
+            src = c->Knm.d();
+            break;
         case EDRGP_GET_LMI: src = c->mats[MAT_LI].d(); n = M * M; break;
         case EDRGP_GET_LBI: src = c->mats[MAT_LBI].d(); n = M * M; break;
         case EDRGP_GET_DLDKMM: src = c->mats[MAT_DKMM].d(); n = M * M; break;
         case EDRGP_GET_SCALARS: src = c->scal.d(); n = 16; break;
-        case EDRGP_GET_MODE: buf[0] = (double)c->last_mode; return EDRGP_OK;
+        case EDRGP_GET_MODE:
+            buf[0] = (double)c->last_mode;
+            if (cap >= 2) buf[1] = c->f32_rho;      // last fp32 guard estimate (0 if the fp32 pass never ran)
+            return EDRGP_OK;
         default: set_error("edrgp_get: unknown selector %d", which); return EDRGP_ERR_INVALID;
     }
     if (!src) { set_error("edrgp_get: object %d not computed yet", which); return EDRGP_ERR_STATE; }
@@ -1029,6 +1163,40 @@ int edrgp_dbg_gemm(edrgp_ctx* ctx, int transA, int transB, int M, int N, int K, 
     if (s == EDRGP_OK && hipStreamSynchronize(c->stream) != hipSuccess) { set_error("dbg_gemm: kernel failed"); s = EDRGP_ERR_HIP; }
     if (s == EDRGP_OK) HIP_TRY(hipMemcpy(C, dC.d(), (size_t)M * ldc * sizeof(double), hipMemcpyDeviceToHost));
     dA.release(); dB.release(); dC.release();
+    return s;
+}
+
+// fp32 building blocks on host float buffers: C = op(A) op(B) (fp32 MFMA), and Phi = K^T K with fp64 slab sums
+int edrgp_dbg_gemm32(edrgp_ctx* ctx, int transA, int transB, int M, int N, int K, const float* A, int lda,
+                     const float* B, int ldb, float* C, int ldc) {
+    CTX(ctx);
+    const size_t ra = transA ? K : M, rb = transB ? N : K;
+    DBuf dA, dB, dC;
+    TRY(dA.reserve(ra * lda * sizeof(float)));
+    TRY(dB.reserve(rb * ldb * sizeof(float)));
+    TRY(dC.reserve((size_t)M * ldc * sizeof(float)));
+    HIP_TRY(hipMemcpy(dA.p, A, ra * lda * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dB.p, B, rb * ldb * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(dC.p, 0, (size_t)M * ldc * sizeof(float)));
+    int s = gemm32(c, transA != 0, transB != 0, M, N, K, static_cast<const float*>(dA.p), lda,
+                   static_cast<const float*>(dB.p), ldb, static_cast<float*>(dC.p), ldc);
+    if (s == EDRGP_OK && hipStreamSynchronize(c->stream) != hipSuccess) { set_error("dbg_gemm32: kernel failed"); s = EDRGP_ERR_HIP; }
+    if (s == EDRGP_OK) HIP_TRY(hipMemcpy(C, dC.p, (size_t)M * ldc * sizeof(float), hipMemcpyDeviceToHost));
+    dA.release(); dB.release(); dC.release();
+    return s;
+}
+
+int edrgp_dbg_syrk32(edrgp_ctx* ctx, const float* K, int64_t N, int M, double* Phi) {
+    CTX(ctx);
+    if (!K || !Phi || N <= 0 || M <= 0) { set_error("dbg_syrk32: bad input"); return EDRGP_ERR_INVALID; }
+    DBuf dK, dP;
+    TRY(dK.reserve((size_t)N * M * sizeof(float)));
+    TRY(dP.reserve((size_t)M * M * sizeof(double)));
+    HIP_TRY(hipMemcpy(dK.p, K, (size_t)N * M * sizeof(float), hipMemcpyHostToDevice));
+    int s = syrk32_tn(c, static_cast<const float*>(dK.p), N, M, M, dP.d(), M, false);
+    if (s == EDRGP_OK && hipStreamSynchronize(c->stream) != hipSuccess) { set_error("dbg_syrk32: kernel failed"); s = EDRGP_ERR_HIP; }
+    if (s == EDRGP_OK) HIP_TRY(hipMemcpy(Phi, dP.d(), (size_t)M * M * sizeof(double), hipMemcpyDeviceToHost));
+    dK.release(); dP.release();
     return s;
 }
 

@@ -176,6 +176,19 @@ int predict_chunk(Ctx* c, const KSpec& ks, const double* Xs, int64_t rows, const
                   int Mp, const double* wv, const double* winv, double kdiag, double* Kbuf, double* Gbuf,
                   double* GT, double* mean, double* var, double* jac);
 int vec_axpy(Ctx* c, int64_t n, double a, const double* x, double* y);   // y += a x
+
+// ------------------------------------------------------- fp32 row pass (la_gemm32.hip)
+int gemm32(Ctx* c, bool transA, bool transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+           float* C, int ldc);
+int syrk32_tn(Ctx* c, const float* K, int64_t rows, int M, int ldk, double* Phi, int ldphi, bool accumulate);
+int gemm32_tn_rows(Ctx* c, int M, int N, int64_t rows, const float* A, int lda, const float* B, int ldb, double* C,
+                   int ldc, bool accumulate);
+int to_f32(Ctx* c, const double* src, size_t n, float* dst);
+int build_xq32(Ctx* c, const double* X, int64_t rows, int D, float* Xq);
+int kernel_matrix32(Ctx* c, const KSpec& ks, const double* X, int64_t rows, const double* Z, int M, float* K32,
+                    const double* y, double* bvec);
+int grad_contract32(Ctx* c, const KSpec& ks, const float* K32, int64_t rows, int M, const float* S2f, const double* y,
+                    const double* wv, double ycoef, float* T32, double* dvar_accum, double* cs);
 int calib_mfma_f64(Ctx* c, double* tflops);
 int calib_mfma_patterns(Ctx* c, double* tflops4);
 int calib_hbm_copy(Ctx* c, double* gbps);
@@ -213,6 +226,15 @@ struct Ctx {
     std::vector<double> lens;         // nparts x D
     double noise_var = 1.0;
     DBuf invl;
+
+    // fp32 row pass (precision == 32): N-proportional storage and MFMA in fp32, M x M work in fp64
+    int precision = 64;
+    double f32_guard = 1.0;           // a-posteriori bound on the relative perturbation of I + A (see sparse_eval)
+    double f32_rho = 0.0;             // last value of that estimate
+    double f32_ratio_max = 1e4;       // fp32 Gram form while (max/min diag Lm)^2 <= this, else the fp64 row pass
+    DBuf Knm32, T32, S2f, Xq32, ks32_x, ks32_z, ks32_xn, ks32_zn;
+    bool xq32_valid = false;
+    bool phi32_bad = false;           // the guard rejected the fp32 Phi for the current data: use the fp64 row pass
 
     // options
     int64_t chunk_rows = 131072;

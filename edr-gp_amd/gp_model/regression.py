@@ -47,10 +47,13 @@ class SparseGaussianProcessRegressor(RegressorMixin, _BaseGP):
         ``num_inducing`` random training rows (global numpy RNG, as GPy does).
     num_inducing : int, default 10 (ignored when Z is given).
     X_variance : must be None.
+    precision : 'fp64' (default) or 'fp32' -- an addition to the reference signature.  'fp32' stores
+        K_nm and runs the gradient contraction on the fp32 MFMA (BASELINE config 5); the bound itself
+        uses the fp32 Gram matrix only when an a-posteriori check accepts it, otherwise fp64.
     """
 
     def __init__(self, kernels=None, kernel_options=None, Z=None, num_inducing=10, Y_metadata=None,
-                 X_variance=None, normalizer=True, mean_function=None, method="optimize"):
+                 X_variance=None, normalizer=True, mean_function=None, method="optimize", precision="fp64"):
         self.kernels = kernels
         self.kernel_options = kernel_options
         self.Z = Z
@@ -60,10 +63,13 @@ class SparseGaussianProcessRegressor(RegressorMixin, _BaseGP):
         self.normalizer = normalizer
         self.mean_function = mean_function
         self.method = method
+        self.precision = precision
 
     def _get_model(self, X, y, kernel):
+        if self.precision not in ("fp64", "fp32"):
+            raise ValueError("precision must be 'fp64' or 'fp32'")
         if self.Y_metadata is not None:
             raise NotImplementedError("Y_metadata is GPy-specific and not supported")
         return SparseGPRegressionModel(X, y, kernel=kernel, Z=self.Z, num_inducing=self.num_inducing,
                                        X_variance=self.X_variance, mean_function=self.mean_function,
-                                       normalizer=self.normalizer)
+                                       normalizer=self.normalizer, precision=32 if self.precision == "fp32" else 64)

@@ -112,9 +112,14 @@ class HipEvaluator:
         if not resident:
             self._sent = {}
         h = self._ctx.hip
+        prec = int(getattr(model, "precision", 64))
+        if self._sent.get("prec") != prec:
+            h.set_option("precision", prec)
+            self._sent["prec"] = prec
+            self._sent.pop("post", None)
         if self._sent.get("data") is not model._data_version:
             h.set_data(model.X, model.Y_normalized[:, 0])
-            self._sent = {"data": model._data_version}
+            self._sent = {"data": model._data_version, "prec": prec}
         if model.is_sparse:
             zkey = model.Z.tobytes()
             if self._sent.get("Z") != zkey:
@@ -420,10 +425,14 @@ class SparseGPRegressionModel(_GPModel):
     is_sparse = True
 
     def __init__(self, X, Y, kernel=None, Z=None, num_inducing=10, X_variance=None, mean_function=None,
-                 normalizer=None, evaluator=None, device=None):
+                 normalizer=None, evaluator=None, device=None, precision=64):
         if X_variance is not None or mean_function is not None:
             raise NotImplementedError("X_variance / mean_function are GPy-specific and not supported")
+        if precision not in (32, 64):
+            raise ValueError("precision must be 32 or 64")
         super().__init__(X, Y, kernel, 1.0, normalizer, evaluator, device)
+        # 32: the row pass of the native path in fp32 where that is safe (include/edrgp_hip.h, "precision")
+        self.precision = precision
         if Z is None:
             i = np.random.permutation(self.num_data)[:min(num_inducing, self.num_data)]
             Z = self.X[i].copy()
@@ -449,6 +458,7 @@ class SparseGPRegressionModel(_GPModel):
     def to_dict(self):
         d = super().to_dict()
         d["Z"] = self.Z
+        d["precision"] = np.array(self.precision)
         return d
 
 
@@ -462,7 +472,8 @@ def load_model(path, evaluator=None, device=None):
         normalizer = bool(f["normalize"])
         if str(f["model"]) == "SparseGPRegressionModel":
             m = SparseGPRegressionModel(f["X"], f["Y"], kernel, Z=f["Z"], normalizer=normalizer,
-                                        evaluator=evaluator, device=device)
+                                        evaluator=evaluator, device=device,
+                                        precision=int(f["precision"]) if "precision" in f.files else 64)
         else:
             m = GPRegressionModel(f["X"], f["Y"], kernel, normalizer=normalizer, evaluator=evaluator, device=device)
         m.noise_variance = float(f["noise_variance"])

@@ -84,7 +84,11 @@ int  edrgp_sync(edrgp_ctx* ctx);
  * 1 Gram form Phi = K_mn K_nm, 2 stable form via K_nm Lm^-T), "pivot_ratio_max",
  * "overlap" (side-stream use: 0 none, 1 the Kmm gradient term beside the gradient contraction,
  * 2 also the Kmm Cholesky beside the row pass, 3 (default) = 2 for bound-only and 1 for
- * gradient evaluations) */
+ * gradient evaluations), "precision" (64 default; 32 = BASELINE config 5: K_nm, the Phi
+ * contraction and the gradient contraction stored / multiplied in fp32 on the fp32 MFMA,
+ * slab sums and every M x M object fp64; used for single-part kernels (D <= 64 for gradients)
+ * while the Gram form is safe in fp32, (max/min diag Lm)^2 <= "f32_ratio_max" (default 1e4),
+ * otherwise the evaluation runs the fp64 row pass; EDRGP_GET_MODE reports 3 when fp32 ran) */
 int  edrgp_set_option(edrgp_ctx* ctx, const char* key, double value);
 
 /* Training data (already validated / normalised by the host: check_X_y at
@@ -146,6 +150,10 @@ int  edrgp_comm_destroy(edrgp_ctx* ctx);
 int  edrgp_dbg_gemm(edrgp_ctx* ctx, int transA, int transB, int M, int N, int K,
                     double alpha, const double* A, int lda, const double* B, int ldb,
                     double beta, double* C, int ldc);
+/* fp32 building blocks of the "precision" = 32 row pass (fp32 MFMA; Phi slabs summed in fp64) */
+int  edrgp_dbg_gemm32(edrgp_ctx* ctx, int transA, int transB, int M, int N, int K,
+                      const float* A, int lda, const float* B, int ldb, float* C, int ldc);
+int  edrgp_dbg_syrk32(edrgp_ctx* ctx, const float* K, int64_t N, int M, double* Phi);
 int  edrgp_dbg_potrf(edrgp_ctx* ctx, double* A, int n, int* info);
 int  edrgp_dbg_diag_stamps(edrgp_ctx* ctx, const double* A64x64, int do_chol, double* stamps6);
 int  edrgp_dbg_trtri(edrgp_ctx* ctx, const double* L, double* Linv, int n);

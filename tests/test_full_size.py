@@ -102,3 +102,33 @@ def test_full_size_properties(hip, name, N, M, D, kind):
     finally:
         hip.set_option("stats_mode", 0)
         hip.set_option("chunk_rows", 131072)
+
+
+def test_c5_full_size_fp32_row_pass(hip):
+    """BASELINE config 5 (N=2M, M=4096, D=64, RBF, fp32 path) at full size, checked against the
+    fp64 device path on the same inputs (itself pinned to the oracle at small sizes and by the
+    properties above).  Tolerances: if the guard accepts the fp32 Gram matrix (mode 3) the bound
+    agrees to 1e-4, otherwise the bound is the fp64 one (1e-10); the fp32 gradient contraction
+    gives d/dvariance, d/dlengthscale to 1e-2 and dZ to 0.15 (max-norm relative; 1.7e-3 / 3.1e-3 /
+    6.7e-2 observed) and leaves d/dnoise (M x M scalars only) at 1e-10 when the bound is fp64."""
+    N, M, D = 2000000, 4096, 64
+    X, y, Z = synthetic(N, D, M, seed=1)
+    ls = np.full((1, D), np.sqrt(D))
+    hip.set_option("precision", 32)
+    try:
+        hip.set_data(X, y)
+        hip.set_inducing(Z)
+        hip.set_kernel(["RBF"], [1.0], ls, 0.01)
+        lml32, dvar32, dlen32, dnoise32, dZ32 = hip.sparse_lml_grad()
+        mode = int(hip.get("MODE", (2,))[0])
+        hip.set_option("precision", 64)
+        lml64, dvar64, dlen64, dnoise64, dZ64 = hip.sparse_lml_grad()
+    finally:
+        hip.set_option("precision", 64)
+    assert np.isfinite(lml32) and mode in (1, 2, 3)
+    btol = 1e-4 if mode == 3 else 1e-10
+    assert abs(lml32 - lml64) <= btol * abs(lml64)
+    assert abs(dnoise32 - dnoise64) <= max(btol, 1e-10) * 10 * abs(dnoise64)
+    assert abs(dvar32[0] - dvar64[0]) <= 1e-2 * abs(dvar64[0])
+    assert np.abs(dlen32 - dlen64).max() <= 1e-2 * np.abs(dlen64).max()
+    assert np.abs(dZ32 - dZ64).max() <= 0.15 * np.abs(dZ64).max()
