@@ -596,6 +596,9 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
             TRY(c->bpart.reserve((size_t)tiles_m * M * sizeof(double)));
             TRY(c->g2.reserve(((size_t)M * 2 * D + M + 8) * sizeof(double)));
             f.cspart = c->bpart.d();
+            // RBF: the epilogue reads k from the resident K_nm chunk instead of recomputing distances
+            f.K = (c->kind[0] == EDRGP_KERN_RBF && c->rbf_epilogue) ? c->Knm.d() : nullptr;
+            f.ldk = M;
             double* G2 = c->g2.d();
             double* csv = G2 + (size_t)M * 2 * D;
             GemmOpts o;
@@ -911,6 +914,7 @@ int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
     else if (!std::strcmp(key, "fuse_grad")) c->fuse_grad = (value != 0.0);
     else if (!std::strcmp(key, "tri_tile")) g_tri_tile = (int)value;
     else if (!std::strcmp(key, "mfma_kbuild")) c->mfma_kbuild = (value != 0.0);
+    else if (!std::strcmp(key, "rbf_epilogue")) c->rbf_epilogue = (value != 0.0);
     else if (!std::strcmp(key, "f32_ratio_max")) c->f32_ratio_max = value;
     else if (!std::strcmp(key, "f32_guard")) c->f32_guard = value;
     else if (!std::strcmp(key, "precision")) {

@@ -75,6 +75,8 @@ struct FuseT {
     const double* invl;     // D
     double* dvpart;         // one partial per workgroup
     double* cspart;         // tiles_m x M partial column sums of T (or null)
+    const double* K;        // RBF only (or null): the resident K_nm chunk, h(r) = -k(r) needs no distances
+    int ldk;
     double ycoef, var;
     int D, kind;
 };
@@ -124,6 +126,7 @@ int gemm(Ctx* c, bool transA, bool transB, int M, int N, int K, double alpha,
 int syrk_tn(Ctx* c, const double* K, int64_t rows, int M, int ldk, double* Phi, int ldphi,
             bool accumulate);
 
+int pick_syrk_splits(Ctx* c, long long nt, int kt, int64_t rows, int M, int tile, int elem_bytes);
 int slab_reduce_mirror(Ctx* c, const double* slabs, int splits, long long slabStride, int M, double* Phi);
 // experimental variants (exp_syrk.hip)
 int syrk_variant(Ctx* c, const double* K, int rows, int M, int ld, int variant, int splits, double* Phi);
@@ -206,6 +209,7 @@ struct Ctx {
     int overlap = 3;                  // 0 none; 1 Kmm gradient term beside the gradient contraction;
                                       // 2 also phase 1 beside the row pass (stretches the Phi kernel);
                                       // 3 = 2 for bound-only evaluations, 1 for gradient evaluations
+    bool rbf_epilogue = true;         // RBF: fused gradient epilogue takes h(r) = -k(r) from the resident K_nm
     bool fuse_grad = true;            // fused Q .* h epilogue of the gradient contraction (single-part kernels, D <= 32)
     int gemm_dephase = 3;             // see la_gemm.hip: 3 = staging / barrier phases at raised priority
     bool trace = false;

@@ -379,6 +379,60 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         double* Xs = &As[0][0];
         double* Zs = &Bs[0][0];
         const FuseT& f = g.fuse;
+        if (f.K != nullptr) {
+            // RBF: h(r) = (dk/dr)/r = -k(r), and k is the resident K_nm tile this workgroup's rows and
+            // columns address -- no distances, no exp.  (k == var  <=>  r == 0, where T is 0 upstream.)
+            double wvc[TN], csum[TN];
+#pragma unroll
+            for (int y = 0; y < TN; ++y) {
+                const int col = n0 + wn * WN + y * 16 + lr;
+                wvc[y] = (col < g.N) ? f.wv[col] : 0.0;
+                csum[y] = 0.0;
+            }
+            double dv = 0.0;
+#pragma unroll
+            for (int x = 0; x < TM; ++x)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + wm * WM + x * 16 + lq + 4 * r;
+                    const double yr = (row < Meff) ? f.ycoef * f.y[row] : 0.0;
+#pragma unroll
+                    for (int y = 0; y < TN; ++y) {
+                        const int col = n0 + wn * WN + y * 16 + lr;
+                        if (row < Meff && col < g.N) {
+                            const double Kv = f.K[(size_t)row * f.ldk + col];
+                            const double Q = fma(yr, wvc[y], acc[x][y][r]);
+                            dv = fma(Q, Kv, dv);
+                            const double tval = (Kv == f.var) ? 0.0 : -(Q * Kv);
+                            C[(size_t)row * g.ldc + col] = tval;
+                            csum[y] += tval;
+                        }
+                    }
+                }
+            if (f.cspart != nullptr) {
+                __syncthreads();
+                double* redc = &Bs[0][0];
+#pragma unroll
+                for (int y = 0; y < TN; ++y) redc[((wm * 4 + lq) * BN) + wn * WN + y * 16 + lr] = csum[y];
+                __syncthreads();
+                for (int j = tid; j < BN; j += 256) {
+                    double sum = 0.0;
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) sum += redc[p * BN + j];
+                    if (n0 + j < g.N) f.cspart[(size_t)ti * g.N + n0 + j] = sum;
+                }
+            }
+            __syncthreads();
+            double* red = &As[0][0];
+            red[tid] = dv;
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) {
+                if (tid < o) red[tid] += red[tid + o];
+                __syncthreads();
+            }
+            if (tid == 0) f.dvpart[(size_t)blockIdx.z * gridDim.x + blockIdx.x] = red[0] / f.var;
+            return;
+        }
         // one feature chunk (the host fuses only when D <= DC): stage, then one row block
         // of accumulators at a time to keep the register footprint at acc + 16 doubles
         __syncthreads();
@@ -638,6 +692,27 @@ int slab_reduce_mirror(Ctx* c, const double* slabs, int splits, long long slabSt
     return EDRGP_OK;
 }
 
+// Split count of the Phi contraction.  2 workgroups per CU are resident, so the launch runs in
+// rounds of 2 * num_cu workgroups and a nearly empty last round costs a whole round (5 % at Cm with a
+// 25 %-full 5th round, 23 % at M = 4096 with 3 splits).  Cost model per candidate s:
+//   rounds(s) * (work of one workgroup ~ 1/s)  +  slab traffic s * 2 M^2 elements,
+// minimised over s with >= 256 rows per split.
+int pick_syrk_splits(Ctx* c, long long nt, int kt, int64_t rows, int M, int tile, int elem_bytes) {
+    const long long slots = 2LL * c->num_cu;
+    const int max_splits = std::max(1, std::min(64, kt / 16));
+    const double wg_rate = (elem_bytes == 8 ? 62e12 : 128e12) / (double)slots;        // flop/s per resident workgroup
+    const double t_full = 2.0 * (double)rows * tile * tile / wg_rate;                  // one workgroup over all rows
+    const double t_slab = 2.0 * (double)M * M * elem_bytes / 3.0e12;                   // write + read of one slab
+    int best = 1;
+    double best_cost = 1e300;
+    for (int s = 1; s <= max_splits; ++s) {
+        const long long rounds = (nt * s + slots - 1) / slots;
+        const double cost = (double)rounds * t_full / s + s * t_slab;
+        if (cost < best_cost * (1.0 - 1e-3)) { best_cost = cost; best = s; }
+    }
+    return best;
+}
+
 int syrk_tn(Ctx* c, const double* K, int64_t rows, int M, int ldk, double* Phi, int ldphi, bool accumulate) {
     if (rows > 0x7fffffffLL) { set_error("syrk_tn: rows chunk too large"); return EDRGP_ERR_INVALID; }
     const int tile = (M >= 256) ? 128 : 64;
@@ -645,14 +720,7 @@ int syrk_tn(Ctx* c, const double* K, int64_t rows, int M, int ldk, double* Phi, 
     const long long nt = (long long)tm * (tm + 1) / 2;
     const int kt = (int)((rows + BK - 1) / BK);
     int splits = c->syrk_splits;
-    if (splits <= 0) {
-        // 2 workgroups per CU are resident: fill whole rounds of 2 * num_cu
-        // workgroups (4 rounds) and never start a nearly empty extra round.
-        const long long slots = 2LL * c->num_cu;
-        splits = (int)std::max<long long>(1, (4 * slots) / nt);
-        const int max_splits = std::max(1, kt / 16);          // >= 256 rows per split
-        if (splits > max_splits) splits = max_splits;
-    }
+    if (splits <= 0) splits = pick_syrk_splits(c, nt, kt, rows, M, tile, 8);
     if (splits < 1) splits = 1;
     if (splits > kt) splits = std::max(1, kt);
     const long long slabStride = (long long)M * M;

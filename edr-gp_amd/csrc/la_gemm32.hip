@@ -318,11 +318,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(G32Args g) {
         float* Xs = &As[0][0];
         float* Zs = &Bs[0][0];
         const Fuse32T& f = g.ft;
+        const bool rbf = (f.kind == EDRGP_KERN_RBF);        // h(r) = -k(r): k is the A operand itself
         __syncthreads();
+        if (!rbf)
         for (int e = tid; e < BM * f.D; e += 256) {
             const int i = e / f.D, q = e - i * f.D;
             Xs[q * BM + i] = (m0 + i < g.M) ? f.Xs[(size_t)(m0 + i) * f.D + q] : 0.0f;
         }
+        if (!rbf)
         for (int e = tid; e < BN * f.D; e += 256) {
             const int j = e / f.D, q = e - j * f.D;
             Zs[q * BN + j] = (n0 + j < g.N) ? f.Zs[(size_t)(n0 + j) * f.D + q] : 0.0f;
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(G32Args g) {
             for (int y = 0; y < TN; ++y)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) r2[y][r] = 0.0f;
-            for (int q = 0; q < f.D; ++q) {
+            for (int q = 0; !rbf && q < f.D; ++q) {
                 float zc[TN];
 #pragma unroll
                 for (int y = 0; y < TN; ++y) zc[y] = Zs[q * BN + wn * WN + y * 16 + lr];
@@ -367,9 +370,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(G32Args g) {
                     if (row < g.M && col < g.N) {
                         const float Q = fmaf(yr, wvc[y], acc[x][y][r]);
                         float Kv, hv;
-                        kfun32(f.kind, f.var, r2[y][r], Kv, hv);
+                        bool zero;
+                        if (rbf) {
+                            Kv = A[(size_t)row * g.lda + col];
+                            hv = -Kv;
+                            zero = (Kv == f.var);
+                        } else {
+                            kfun32(f.kind, f.var, r2[y][r], Kv, hv);
+                            zero = (r2[y][r] == 0.0f);
+                        }
                         dvx = fmaf(Q, Kv, dvx);
-                        const float tval = (r2[y][r] == 0.0f) ? 0.0f : Q * hv;
+                        const float tval = zero ? 0.0f : Q * hv;
                         C[(size_t)row * g.ldc + col] = tval;
                         csum[y] += tval;
                     }
@@ -525,9 +536,8 @@ int syrk32_tn(Ctx* c, const float* K, int64_t rows, int M, int ldk, double* Phi,
     const int kt = (int)((rows + BK32 - 1) / BK32);
     int splits = c->syrk_splits;
     if (splits <= 0) {
-        // whole rounds of 2 * num_cu resident workgroups, at most 8192 rows per fp32 accumulation chain
-        const long long slots = 2LL * c->num_cu;
-        splits = (int)std::max<long long>(1, (4 * slots) / nt);
+        // rounds-aware choice (la_gemm.hip), then at most 8192 rows per fp32 accumulation chain
+        splits = pick_syrk_splits(c, nt, kt / 2, rows, M, tile, 4);
         const int by_len = (int)((rows + 8191) / 8192);
         if (splits < by_len) splits = by_len;
         const int max_splits = std::max(1, kt / 8);           // >= 256 rows per split
