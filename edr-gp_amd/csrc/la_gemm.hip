@@ -390,6 +390,44 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                 csum[y] = 0.0;
             }
             double dv = 0.0;
+            const bool interior = (m0 + BM <= Meff) && (n0 + BN <= g.N) &&
+                                  ((long long)BM * f.ldk < (1LL << 28)) && ((long long)BM * g.ldc < (1LL << 28));
+            if (interior) {
+                // Interior tiles: wave-uniform row bases (SGPRs) + one per-lane byte offset, so an element
+                // costs a load, a store and ~5 VALU instructions -- beside the partner workgroup's MFMA stream
+                // every further VALU instruction of this epilogue is paid at ~1 per MFMA issue slot.
+                const int wu = __builtin_amdgcn_readfirstlane(wave);
+                const int wmu = wu >> 1, wnu = wu & 1;
+                const char* Kb = reinterpret_cast<const char*>(f.K + (size_t)(m0 + wmu * WM) * f.ldk + n0 + wnu * WN);
+                char* Cb = reinterpret_cast<char*>(C + (size_t)(m0 + wmu * WM) * g.ldc + n0 + wnu * WN);
+                const double* yb = f.y + m0 + wmu * WM;
+                const unsigned vk = (unsigned)((lq * f.ldk + lr) * 8), vc = (unsigned)((lq * g.ldc + lr) * 8);
+                const double nvar = f.var;
+#pragma unroll
+                for (int x = 0; x < TM; ++x) {
+                    double kv[4][TN], yr[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const char* kr = Kb + (size_t)(x * 16 + 4 * r) * f.ldk * 8;
+                        yr[r] = yb[x * 16 + 4 * r + lq];
+#pragma unroll
+                        for (int y = 0; y < TN; ++y) kv[r][y] = *reinterpret_cast<const double*>(kr + vk + y * 128);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        char* cr = Cb + (size_t)(x * 16 + 4 * r) * g.ldc * 8;
+                        const double ys = f.ycoef * yr[r];
+#pragma unroll
+                        for (int y = 0; y < TN; ++y) {
+                            const double Q = fma(ys, wvc[y], acc[x][y][r]);
+                            dv = fma(Q, kv[r][y], dv);
+                            const double tval = (kv[r][y] == nvar) ? 0.0 : -(Q * kv[r][y]);
+                            *reinterpret_cast<double*>(cr + vc + y * 128) = tval;
+                            csum[y] += tval;
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int x = 0; x < TM; ++x)
 #pragma unroll
