@@ -142,6 +142,47 @@ struct SideStream {
     }
 };
 
+// CU-masked streams (hipExtStreamCreateWithCUMask).  Mask bit b is CU b/8 of XCD b%8 on this part, so the
+// low `side_cus` bits give the side stream side_cus/8 CUs in every XCD.
+static bool ensure_masked_streams(Ctx* c) {
+    if (c->masked_state != 0) return c->masked_state > 0;
+    c->masked_state = -1;
+    const int ncu = c->num_cu, side = c->side_cus;
+    if (side <= 0 || side >= ncu / 2 || ncu > 512) return false;
+    uint32_t m_side[16] = {0}, m_main[16] = {0};
+    // mask_layout 1 (default): the low `side` bits.  Measured on MI355X: consecutive mask bits go to
+    //   consecutive XCDs, so this gives every XCD side/8 CUs (side = 32: 11.8 ms per bound evaluation at Cm
+    //   vs 12.2 unmasked; 8 or 16 CUs are too few for the O(M^3) phase: 14-15 ms).
+    // mask_layout 0: side/8 bits at the start of each block of ncu/8 bits (15 ms: unbalances the XCDs).
+    const int per_xcd = std::max(1, ncu / 8), per_side = std::max(1, side / 8);
+    for (int b = 0; b < ncu; ++b) {
+        const bool is_side = (c->mask_layout == 0) ? ((b % per_xcd) < per_side && (b / per_xcd) < 8) : (b < side);
+        (is_side ? m_side : m_main)[b >> 5] |= (1u << (b & 31));
+    }
+    const uint32_t words = (uint32_t)((ncu + 31) / 32);
+    if (hipExtStreamCreateWithCUMask(&c->stream_mm, words, m_main) != hipSuccess) { (void)hipGetLastError(); c->stream_mm = nullptr; return false; }
+    if (hipExtStreamCreateWithCUMask(&c->stream_ms, words, m_side) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamDestroy(c->stream_mm);
+        c->stream_mm = c->stream_ms = nullptr;
+        return false;
+    }
+    c->masked_state = 1;
+    return true;
+}
+
+struct MaskedScope {                    // while active, c->stream / c->stream2 are the masked pair
+    Ctx* c;
+    bool on;
+    MaskedScope(Ctx* c_, bool on_) : c(c_), on(on_) { if (on) swap(+1); }
+    ~MaskedScope() { if (on) swap(-1); }
+    void swap(int dir) {
+        std::swap(c->stream, c->stream_mm);
+        std::swap(c->stream2, c->stream_ms);
+        c->num_cu -= dir * c->side_cus;
+    }
+};
+
 static int main_waits_side(Ctx* c) {       // outside a SideStream scope: c->stream is the main stream
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     return EDRGP_OK;
@@ -370,6 +411,8 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
     // level 3 (default): bound-only evaluations overlap phase 1 (worth 5 % there); gradient evaluations
     // keep the row pass alone on the GPU and use the side stream for the Kmm gradient term only
     const bool want_p1 = (c->overlap == 2) || (c->overlap == 3 && !need_grad);
+    // bound-only evaluations (default policy): masked stream pair, phase 1 gets its own CUs
+    MaskedScope masked(c, c->overlap == 3 && !need_grad && c->side_cus > 0 && !c->comm && ensure_masked_streams(c));
     const bool optimistic = want_p1 && (c->stats_mode == 1 || (c->stats_mode == 0 && c->last_mode != 2));
     const bool ran32 = f32;
     if (optimistic) {
@@ -881,6 +924,8 @@ int edrgp_ctx_destroy(edrgp_ctx* ctx) {
     for (DBuf* b : {&c->ks_x, &c->ks_z, &c->ks_xn, &c->ks_zn, &c->ks_x2, &c->ks_xn2}) b->release();
     (void)hipEventDestroy(c->ev_fork);
     (void)hipEventDestroy(c->ev_join);
+    if (c->stream_mm) (void)hipStreamDestroy(c->stream_mm);
+    if (c->stream_ms) (void)hipStreamDestroy(c->stream_ms);
     (void)hipStreamDestroy(c->stream2);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -915,6 +960,12 @@ int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
     else if (!std::strcmp(key, "tri_tile")) g_tri_tile = (int)value;
     else if (!std::strcmp(key, "mfma_kbuild")) c->mfma_kbuild = (value != 0.0);
     else if (!std::strcmp(key, "rbf_epilogue")) c->rbf_epilogue = (value != 0.0);
+    else if (!std::strcmp(key, "mask_layout")) c->mask_layout = (int)value;
+    else if (!std::strcmp(key, "side_cus")) {
+        // CUs reserved for the side stream of bound-only evaluations (0 = plain streams); takes effect
+        // before the masked streams are first created
+        if (c->masked_state == 0 || (int)value == 0) c->side_cus = (int)value;
+    }
     else if (!std::strcmp(key, "f32_ratio_max")) c->f32_ratio_max = value;
     else if (!std::strcmp(key, "f32_guard")) c->f32_guard = value;
     else if (!std::strcmp(key, "precision")) {

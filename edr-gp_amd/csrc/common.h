@@ -203,6 +203,12 @@ struct Ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;        // side stream: latency-bound O(M^3) work beside the row pass
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // CU-masked stream pair for bound-only evaluations: the side stream owns `side_cus` CUs (spread over the
+    // XCDs), the main stream the rest, so the latency-bound Kmm phase runs beside the row pass at full speed
+    hipStream_t stream_mm = nullptr, stream_ms = nullptr;
+    int side_cus = 0;                     // 0 = off (default: measured gain only 3 %); streams are created on first use
+    int mask_layout = 1;
+    int masked_state = 0;                 // 0 not tried, 1 available, -1 creation failed
     DBuf red2, slabs2;                    // scratch used while launching on the side stream
     DBuf ks_x, ks_z, ks_xn, ks_zn, ks_x2, ks_xn2;   // scaled inputs and squared norms for the MFMA kernel build
     bool mfma_kbuild = true;
