@@ -44,7 +44,8 @@ __global__ __launch_bounds__(64) void diag_block_kernel(double* __restrict__ Aba
                                                         int first_block, double* __restrict__ Dinv,
                                                         double* __restrict__ inv_out, int ldi,
                                                         int* __restrict__ info,
-                                                        unsigned long long* __restrict__ stamps) {
+                                                        unsigned long long* __restrict__ stamps,
+                                                        double* __restrict__ Lbase = nullptr, int ldlo = 0) {
     __shared__ double Lt[NB][NB + 1];      // Lt[k][i] = L[i][k]
     __shared__ double Tl[4][16][17];       // inverses of the 16x16 diagonal blocks, row-major
     __shared__ double rdiag[NB];           // 1 / L[i][i]
@@ -105,6 +106,9 @@ __global__ __launch_bounds__(64) void diag_block_kernel(double* __restrict__ Aba
         if (bad && lane == 0 && info != nullptr) atomicCAS(info, 0, bad);
         __syncthreads();
         EDRGP_STAMP(2);
+        // the factor goes back in place, or (out-of-place potrf) to the same block of Lbase
+        double* Lw = (Lbase != nullptr) ? Lbase + (size_t)j0 * ldlo + j0 : A;
+        const int ldw = (Lbase != nullptr) ? ldlo : lda;
 #pragma unroll 1
         for (int r0 = 0; r0 < NB; r0 += 16) {      // coalesced write-back, explicit zeros above the diagonal
             double t[16];
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(64) void diag_block_kernel(double* __restrict__ Aba
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int r = r0 + u;
-                if (r < jb && lane < jb) A[(size_t)r * lda + lane] = (lane <= r) ? t[u] : 0.0;
+                if (r < jb && lane < jb) Lw[(size_t)r * ldw + lane] = (lane <= r) ? t[u] : 0.0;
             }
         }
     } else {
@@ -228,7 +232,173 @@ __global__ void fill_kernel(double* __restrict__ A, size_t count, double v) {
     for (; i < count; i += stride) A[i] = v;
 }
 
+// One right-looking step behind diagonal block k, ONE launch: for every lower 64x64 tile (i, j),
+// k < j <= i, of the trailing matrix
+//     L_ik = A_ik Dinv^T,  L_jk = A_jk Dinv^T      (recomputed per tile: 2 x 64^3 flops on the matrix pipe
+//                                                   instead of a separate panel launch + its kernel boundary)
+//     A_ij -= L_ik L_jk^T
+// and the tiles of the first trailing column (j = k+1) store L_ik to Lout.  The panel column of A is only
+// read, so there is no ordering between workgroups.  256 threads = 2x2 waves, a wave owns a 32x32 quadrant.
+// LDS: the two operand tiles as [row][k] images (stride 66: conflict-free ds_read_b64 per half-wave), reused
+// for L_ik / L_jk; the Dinv fragments (same for both products) sit in registers.
+__global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ A, int lda, double* __restrict__ Lout,
+                                                           int ldl, const double* __restrict__ Dinv, int n, int k) {
+    constexpr int LS = NB + 2;
+    __shared__ __attribute__((aligned(16))) double R1[NB * LS];
+    __shared__ __attribute__((aligned(16))) double R2[NB * LS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lq = lane >> 4;
+    int ti, tj;
+    {
+        const int t = blockIdx.x;
+        ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        while (ti * (ti + 1) / 2 > t) --ti;
+        tj = t - ti * (ti + 1) / 2;
+    }
+    const int i0 = (k + 1 + ti) * NB, j0 = (k + 1 + tj) * NB, k0 = k * NB;
+    const bool diag = (ti == tj);
+
+    // Dinv fragments: b[st][y] = B[q = 4 st + lq][c = 32 wn + 16 y + lr] = Dinv[c][q]
+    double db[16][2];
+#pragma unroll
+    for (int st = 0; st < 16; ++st)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) db[st][y] = Dinv[(32 * wn + 16 * y + lr) * NB + 4 * st + lq];
+
+    // the tile being updated: loaded now, used in the epilogue (no exposed global latency there)
+    d4 Cij[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + 32 * wm + 16 * x + lq + 4 * r, col = j0 + 32 * wn + 16 * y + lr;
+                Cij[x][y][r] = (row < n && col < n) ? A[(size_t)row * lda + col] : 0.0;
+            }
+    // stage A_ik and A_jk: thread -> rows tid/32 + 8 v, columns 2 (tid % 32), 16-byte loads
+    {
+        const int c2 = (tid & 31) * 2, r8 = tid >> 5;
+        const bool al = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((lda & 1) == 0);
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            const int r = r8 + 8 * v;
+            double2 a1 = {0.0, 0.0}, a2 = {0.0, 0.0};
+            if (i0 + r < n) {
+                const double* p = A + (size_t)(i0 + r) * lda + k0 + c2;
+                if (al) a1 = *reinterpret_cast<const double2*>(p); else { a1.x = p[0]; a1.y = p[1]; }
+            }
+            if (!diag && j0 + r < n) {
+                const double* p = A + (size_t)(j0 + r) * lda + k0 + c2;
+                if (al) a2 = *reinterpret_cast<const double2*>(p); else { a2.x = p[0]; a2.y = p[1]; }
+            }
+            *reinterpret_cast<double2*>(&R1[r * LS + c2]) = a1;
+            if (!diag) *reinterpret_cast<double2*>(&R2[r * LS + c2]) = a2;
+        }
+    }
+    __syncthreads();
+
+    d4 Li[2][2], Lj[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) { Li[x][y] = d4{0.0, 0.0, 0.0, 0.0}; Lj[x][y] = d4{0.0, 0.0, 0.0, 0.0}; }
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+        double a1[2], a2[2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            a1[x] = R1[(32 * wm + 16 * x + lr) * LS + 4 * st + lq];
+            a2[x] = diag ? 0.0 : R2[(32 * wm + 16 * x + lr) * LS + 4 * st + lq];
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                Li[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[x], db[st][y], Li[x][y], 0, 0, 0);
+                if (!diag) Lj[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[x], db[st][y], Lj[x][y], 0, 0, 0);
+            }
+    }
+    __syncthreads();                     // everyone has read the A tiles: overwrite them with L_ik / L_jk
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 32 * wm + 16 * x + lq + 4 * r, col = 32 * wn + 16 * y + lr;
+                R1[row * LS + col] = Li[x][y][r];
+                if (!diag) R2[row * LS + col] = Lj[x][y][r];
+                if (tj == 0 && i0 + row < n) Lout[(size_t)(i0 + row) * ldl + k0 + col] = Li[x][y][r];
+            }
+    __syncthreads();
+
+    const double* Rj = diag ? R1 : R2;
+    d4 S[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) S[x][y] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+        double a[2], b[2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            a[x] = R1[(32 * wm + 16 * x + lr) * LS + 4 * st + lq];
+            b[x] = Rj[(32 * wn + 16 * x + lr) * LS + 4 * st + lq];
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) S[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], S[x][y], 0, 0, 0);
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + 32 * wm + 16 * x + lq + 4 * r, col = j0 + 32 * wn + 16 * y + lr;
+                if (row < n && col < n) A[(size_t)row * lda + col] = Cij[x][y][r] - S[x][y][r];
+            }
+}
+
+// A = lower triangle of L (explicit zeros above the diagonal)
+__global__ void take_lower_kernel(double* __restrict__ A, int lda, const double* __restrict__ L, int ldl, int n) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y * blockDim.y + threadIdx.y;
+    if (i < n && j < n) A[(size_t)i * lda + j] = (j <= i) ? L[(size_t)i * ldl + j] : 0.0;
+}
+
+// Fused-step variant of potrf_lower (same contract): the factor is assembled in the panel workspace and
+// copied back, A is the work matrix of the trailing updates.
+static int potrf_lower_fused(Ctx* c, double* A, int n, int lda, int* info_dev) {
+    HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), c->stream));
+    if (c->dinv.bytes < (size_t)NB * NB * sizeof(double)) {
+        TRY(c->dinv.reserve((size_t)NB * NB * sizeof(double)));
+        HIP_TRY(hipMemsetAsync(c->dinv.d(), 0, (size_t)NB * NB * sizeof(double), c->stream));
+    }
+    TRY(c->panel.reserve((size_t)n * n * sizeof(double)));
+    double* Dinv = c->dinv.d();
+    double* Lw = c->panel.d();
+    const int nblk = (n + NB - 1) / NB;
+    for (int b = 0; b < nblk; ++b) {
+        hipLaunchKernelGGL(diag_block_kernel<true>, dim3(1), dim3(64), 0, c->stream, A, lda, n, b, Dinv,
+                           (double*)nullptr, 0, info_dev, (unsigned long long*)nullptr, Lw, n);
+        const int r = nblk - b - 1;
+        if (r > 0)
+            hipLaunchKernelGGL(chol_step_kernel, dim3((unsigned)(r * (r + 1) / 2)), dim3(256), 0, c->stream, A, lda, Lw, n,
+                               Dinv, n, b);
+    }
+    dim3 blk(64, 4), grd((n + 63) / 64, (n + 3) / 4);
+    hipLaunchKernelGGL(take_lower_kernel, grd, blk, 0, c->stream, A, lda, Lw, n, n);
+    HIP_TRY(hipGetLastError());
+    return EDRGP_OK;
+}
+
 int potrf_lower(Ctx* c, double* A, int n, int lda, int* info_dev) {
+    if (c->chol_fused && n > NB) return potrf_lower_fused(c, A, n, lda, info_dev);
     HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), c->stream));
     if (c->dinv.bytes < (size_t)NB * NB * sizeof(double)) {
         TRY(c->dinv.reserve((size_t)NB * NB * sizeof(double)));
