@@ -40,7 +40,7 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // the inverse into Dinv (dense 64x64, ld 64, blockIdx-th slab; upper blocks are
 // never written and must be zero) and/or into inv_out (ld ldi, jb x jb part).
 template <bool DO_CHOL>
-__global__ __launch_bounds__(64) void diag_block_kernel(double* __restrict__ Abase, int lda, int n,
+__global__ __launch_bounds__(256) void diag_block_kernel(double* __restrict__ Abase, int lda, int n,
                                                         int first_block, double* __restrict__ Dinv,
                                                         double* __restrict__ inv_out, int ldi,
                                                         int* __restrict__ info,
@@ -51,66 +51,72 @@ __global__ __launch_bounds__(64) void diag_block_kernel(double* __restrict__ Aba
     __shared__ double rdiag[NB];           // 1 / L[i][i]
 #define EDRGP_STAMP(slot) do { if (stamps != nullptr && threadIdx.x == 0) stamps[slot] = __builtin_amdgcn_s_memtime(); } while (0)
     EDRGP_STAMP(0);
-    const int lane = threadIdx.x;
+    // 4 waves: all of them move data (load, write-back, the four column chains of the inverse); the
+    // serial factorisation runs on wave 0 alone, ordered through LDS without barriers (one wave's LDS
+    // instructions execute in order).
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int blk = first_block + blockIdx.x;
     const int j0 = blk * NB;
     const int jb = min(NB, n - j0);
     double* A = Abase + (size_t)j0 * lda + j0;
     {
         const int cl = min(lane, jb - 1);
-#pragma unroll 1
-        for (int r0 = 0; r0 < NB; r0 += 32) {       // coalesced, clamped (branch-free), 32 rows in flight
-            double t[32];
+        const int r0 = 16 * wave;                   // coalesced, clamped (branch-free), 16 rows in flight per wave
+        double t[16];
 #pragma unroll
-            for (int u = 0; u < 32; ++u) t[u] = A[(size_t)min(r0 + u, jb - 1) * lda + cl];
+        for (int u = 0; u < 16; ++u) t[u] = A[(size_t)min(r0 + u, jb - 1) * lda + cl];
 #pragma unroll
-            for (int u = 0; u < 32; ++u) {
-                const int r = r0 + u;
-                const bool in = (r < jb) && (lane < jb) && (lane <= r);
-                Lt[lane][r] = in ? t[u] : ((r == lane) ? 1.0 : 0.0);
-            }
+        for (int u = 0; u < 16; ++u) {
+            const int r = r0 + u;
+            const bool in = (r < jb) && (lane < jb) && (lane <= r);
+            Lt[lane][r] = in ? t[u] : ((r == lane) ? 1.0 : 0.0);
         }
     }
     __syncthreads();
     EDRGP_STAMP(1);
 
     if (DO_CHOL) {
-        double a[NB];                                          // row `lane` of A, then of L
+        if (wave == 0) {
+            double a[NB];                                          // row `lane` of A, then of L
 #pragma unroll
-        for (int k = 0; k < NB; ++k) a[k] = Lt[k][lane];
-        __syncthreads();
-        int bad = 0;
+            for (int k = 0; k < NB; ++k) a[k] = Lt[k][lane];
+            int bad = 0;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const double p = readlane_f64(a[j], j);
-            if (!(p > 0.0) && bad == 0) bad = j0 + j + 1;
-            // 1/sqrt(p): v_rsq_f64 + two Newton steps  y <- y (1.5 - 0.5 p y^2)
-            const double hp = 0.5 * p;
-            double y = __builtin_amdgcn_rsq(p);
-            y = y * fma(-hp, y * y, 1.5);
-            y = y * fma(-hp, y * y, 1.5);
-            double l = a[j] * y;                    // lane j: p / sqrt(p) = sqrt(p)
-            if (lane < j) l = 0.0;
-            a[j] = l;
-            if (j + 1 < NB) {
-                // critical path first: the next pivot needs only l[j+1] (one readlane)
-                const double cn = readlane_f64(l, j + 1);
-                a[j + 1] = fma(-l, cn, a[j + 1]);
+            for (int j = 0; j < NB; ++j) {
+                const double p = readlane_f64(a[j], j);
+                if (!(p > 0.0) && bad == 0) bad = j0 + j + 1;
+                // 1/sqrt(p): v_rsq_f64 + two Newton steps  y <- y (1.5 - 0.5 p y^2)
+                const double hp = 0.5 * p;
+                double y = __builtin_amdgcn_rsq(p);
+                y = y * fma(-hp, y * y, 1.5);
+                y = y * fma(-hp, y * y, 1.5);
+                double l = a[j] * y;                    // lane j: p / sqrt(p) = sqrt(p)
+                if (lane < j) l = 0.0;
+                a[j] = l;
+                if (j + 1 < NB) {
+                    // critical path first: the next pivot needs only l[j+1] (one readlane)
+                    const double cn = readlane_f64(l, j + 1);
+                    a[j + 1] = fma(-l, cn, a[j + 1]);
+                }
+                Lt[j][lane] = l;
+                if (lane == j) rdiag[j] = y;
+                // same-wave LDS write -> read needs no s_barrier (one wave's LDS instructions execute in
+                // order); the wavefront-scope fence only keeps the compiler from hoisting every later
+                // iteration's LDS reads above this point (2000 spilled registers without it)
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = j + 2; k < NB; ++k) a[k] = fma(-l, Lt[j][k], a[k]);
             }
-            Lt[j][lane] = l;
-            if (lane == j) rdiag[j] = y;
-            __syncthreads();
-#pragma unroll
-            for (int k = j + 2; k < NB; ++k) a[k] = fma(-l, Lt[j][k], a[k]);
+            if (bad && lane == 0 && info != nullptr) atomicCAS(info, 0, bad);
         }
-        if (bad && lane == 0 && info != nullptr) atomicCAS(info, 0, bad);
         __syncthreads();
         EDRGP_STAMP(2);
         // the factor goes back in place, or (out-of-place potrf) to the same block of Lbase
         double* Lw = (Lbase != nullptr) ? Lbase + (size_t)j0 * ldlo + j0 : A;
         const int ldw = (Lbase != nullptr) ? ldlo : lda;
-#pragma unroll 1
-        for (int r0 = 0; r0 < NB; r0 += 16) {      // coalesced write-back, explicit zeros above the diagonal
+        {
+            const int r0 = 16 * wave;               // coalesced write-back, explicit zeros above the diagonal
             double t[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) t[u] = Lt[lane][r0 + u];          // 16 LDS reads in flight
@@ -121,14 +127,14 @@ __global__ __launch_bounds__(64) void diag_block_kernel(double* __restrict__ Aba
             }
         }
     } else {
-        rdiag[lane] = 1.0 / Lt[lane][lane];
+        if (wave == 0) rdiag[lane] = 1.0 / Lt[lane][lane];
         __syncthreads();
         EDRGP_STAMP(2);
     }
     EDRGP_STAMP(3);
 
-    // ---- inverse, step 1: T_b = inv(L_bb) for the four 16x16 diagonal blocks
-    {
+    // ---- inverse, step 1 (wave 0): T_b = inv(L_bb) for the four 16x16 diagonal blocks
+    if (wave == 0) {
         const int b = lane >> 4, cidx = lane & 15, o = 16 * b;
         double t[16];
 #pragma unroll
@@ -145,56 +151,64 @@ __global__ __launch_bounds__(64) void diag_block_kernel(double* __restrict__ Aba
     }
     __syncthreads();
 
-    // ---- inverse, step 2: block substitution on the matrix pipe
+    // ---- inverse, step 2: block substitution on the matrix pipe; wave w owns block column j = w
+    // (X_jj, then X_ij for i > j, each a chain through the tiles above it in the same column)
     const int lr = lane & 15, lq = lane >> 4;
-    d4 X[4][4];                                   // X[i][j], i >= j, C/D layout: reg r = row lq + 4r, col lr
+    const int j = wave;
+    d4 X[4];                                      // X[i] = X_ij, i >= j, C/D layout: reg r = row lq + 4r, col lr
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int i = 0; i < 4; ++i) X[i] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) X[j][j][r] = Tl[j][lq + 4 * r][lr];
+    for (int jj = 0; jj < 4; ++jj)
+        if (jj == j) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+            for (int r = 0; r < 4; ++r) X[jj][r] = Tl[jj][lq + 4 * r][lr];
+        }
 #pragma unroll
-        for (int i = j + 1; i < 4; ++i) {
+    for (int i = 1; i < 4; ++i) {
+        if (i > j) {
             d4 S = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int k = j; k < i; ++k)
+            for (int k = 0; k < i; ++k) {
+                if (k >= j) {
 #pragma unroll
-                for (int st = 0; st < 4; ++st) {
-                    // A fragment of L_ik: lane holds L[16i + lr][16k + 4 st + lq]
-                    const double af = Lt[16 * k + 4 * st + lq][16 * i + lr];
-                    S = __builtin_amdgcn_mfma_f64_16x16x4f64(af, X[k][j][st], S, 0, 0, 0);
+                    for (int st = 0; st < 4; ++st) {
+                        // A fragment of L_ik: lane holds L[16i + lr][16k + 4 st + lq]
+                        const double af = Lt[16 * k + 4 * st + lq][16 * i + lr];
+                        S = __builtin_amdgcn_mfma_f64_16x16x4f64(af, X[k][st], S, 0, 0, 0);
+                    }
                 }
+            }
             d4 Y = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 const double tf = -Tl[i][lr][4 * st + lq];          // A fragment of -T_ii
                 Y = __builtin_amdgcn_mfma_f64_16x16x4f64(tf, S[st], Y, 0, 0, 0);
             }
-            X[i][j] = Y;
+            X[i] = Y;
         }
     }
     EDRGP_STAMP(4);
     if (Dinv) {
         double* D = Dinv + (size_t)blockIdx.x * NB * NB;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i)
+            if (i >= j) {
 #pragma unroll
-            for (int i = j; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) D[(16 * i + lq + 4 * r) * NB + 16 * j + lr] = X[i][j][r];
+                for (int r = 0; r < 4; ++r) D[(16 * i + lq + 4 * r) * NB + 16 * j + lr] = X[i][r];
+            }
     }
     if (inv_out) {
         double* O = inv_out + (size_t)j0 * ldi + j0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = j; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
+            if (i >= j) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * i + lq + 4 * r, col = 16 * j + lr;
-                    if (row < jb && col < jb) O[(size_t)row * ldi + col] = X[i][j][r];
+                    if (row < jb && col < jb) O[(size_t)row * ldi + col] = X[i][r];
                 }
+            }
     }
     EDRGP_STAMP(5);
 #undef EDRGP_STAMP
@@ -204,10 +218,10 @@ __global__ __launch_bounds__(64) void diag_block_kernel(double* __restrict__ Aba
 int diag_block_stamps(Ctx* c, double* A64, double* Dinv64, unsigned long long* stamps_dev, int do_chol) {
     HIP_TRY(hipMemsetAsync(Dinv64, 0, NB * NB * sizeof(double), c->stream));
     if (do_chol)
-        hipLaunchKernelGGL(diag_block_kernel<true>, dim3(1), dim3(64), 0, c->stream, A64, 64, 64, 0, Dinv64,
+        hipLaunchKernelGGL(diag_block_kernel<true>, dim3(1), dim3(256), 0, c->stream, A64, 64, 64, 0, Dinv64,
                            (double*)nullptr, 0, (int*)nullptr, stamps_dev);
     else
-        hipLaunchKernelGGL(diag_block_kernel<false>, dim3(1), dim3(64), 0, c->stream, A64, 64, 64, 0, Dinv64,
+        hipLaunchKernelGGL(diag_block_kernel<false>, dim3(1), dim3(256), 0, c->stream, A64, 64, 64, 0, Dinv64,
                            (double*)nullptr, 0, (int*)nullptr, stamps_dev);
     HIP_TRY(hipGetLastError());
     return EDRGP_OK;
@@ -384,7 +398,7 @@ static int potrf_lower_fused(Ctx* c, double* A, int n, int lda, int* info_dev) {
     double* Lw = c->panel.d();
     const int nblk = (n + NB - 1) / NB;
     for (int b = 0; b < nblk; ++b) {
-        hipLaunchKernelGGL(diag_block_kernel<true>, dim3(1), dim3(64), 0, c->stream, A, lda, n, b, Dinv,
+        hipLaunchKernelGGL(diag_block_kernel<true>, dim3(1), dim3(256), 0, c->stream, A, lda, n, b, Dinv,
                            (double*)nullptr, 0, info_dev, (unsigned long long*)nullptr, Lw, n);
         const int r = nblk - b - 1;
         if (r > 0)
@@ -410,7 +424,7 @@ int potrf_lower(Ctx* c, double* A, int n, int lda, int* info_dev) {
     for (int b = 0; b < nblk; ++b) {
         const int j0 = b * NB;
         const int jb = std::min(NB, n - j0);
-        hipLaunchKernelGGL(diag_block_kernel<true>, dim3(1), dim3(64), 0, c->stream, A, lda, n, b, Dinv,
+        hipLaunchKernelGGL(diag_block_kernel<true>, dim3(1), dim3(256), 0, c->stream, A, lda, n, b, Dinv,
                            (double*)nullptr, 0, info_dev, (unsigned long long*)nullptr);
         const int rem = n - j0 - jb;
         if (rem > 0) {
@@ -448,7 +462,7 @@ int trtri_lower(Ctx* c, const double* L, int ldl, double* Linv, int ldi, int n) 
         }
     }
     const int nblk = (n + NB - 1) / NB;
-    hipLaunchKernelGGL(diag_block_kernel<false>, dim3(nblk), dim3(64), 0, c->stream, const_cast<double*>(L), ldl,
+    hipLaunchKernelGGL(diag_block_kernel<false>, dim3(nblk), dim3(256), 0, c->stream, const_cast<double*>(L), ldl,
                        n, 0, (double*)nullptr, Linv, ldi, (int*)nullptr, (unsigned long long*)nullptr);
     HIP_TRY(hipGetLastError());
     if (n <= NB) return EDRGP_OK;
