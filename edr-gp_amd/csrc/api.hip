@@ -447,7 +447,9 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
             HIP_TRY(hipMemcpyAsync(v_v, bvec, (size_t)M * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         } else {
             TRY(gemm(c, false, false, M, M, M, 1.0, Li, M, Phi, M, 0.0, Tm, M, kopt(K_LE_ROW)));
-            TRY(gemm(c, false, true, M, M, M, beta, Tm, M, Li, M, 0.0, A, M, kopt(K_LE_COL)));
+            // A = beta (Li Phi) Li^T is symmetric: lower tiles only, then mirrored
+            TRY(gemm(c, false, true, M, M, M, beta, Tm, M, Li, M, 0.0, A, M, kopt(K_LE_COL, 1)));
+            TRY(mirror_lower(c, A, M, M));
             TRY(gemv_n(c, M, M, 1.0, Li, M, bvec, v_v));
         }
         TRY(trace_of(c, A, M, M, sc + SC_TRA));
