@@ -51,6 +51,8 @@ PROTOTYPES = {
     "edrgp_sync": [_ctx_p],
     "edrgp_set_option": [_ctx_p, ctypes.c_char_p, ctypes.c_double],
     "edrgp_set_data": [_ctx_p, _c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int],
+    "edrgp_set_data_projected": [_ctx_p, _c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int, _c_double_p,
+                                 ctypes.c_int],
     "edrgp_set_inducing": [_ctx_p, _c_double_p, ctypes.c_int],
     "edrgp_set_kernel": [_ctx_p, ctypes.c_int, _c_int_p, _c_double_p, _c_double_p, ctypes.c_double],
     "edrgp_sparse_lml": [_ctx_p, _c_double_p],
@@ -61,6 +63,7 @@ PROTOTYPES = {
     "edrgp_predict": [_ctx_p, _c_double_p, ctypes.c_int64, _c_double_p, _c_double_p],
     "edrgp_predict_grad": [_ctx_p, _c_double_p, ctypes.c_int64, _c_double_p],
     "edrgp_predict_train": [_ctx_p, _c_double_p, _c_double_p],
+    "edrgp_predict_train_gram": [_ctx_p, _c_double_p, _c_double_p, _c_double_p],
     "edrgp_get": [_ctx_p, ctypes.c_int, _c_double_p, ctypes.c_int64],
     "edrgp_profile_reset": [_ctx_p],
     "edrgp_profile_get": [_ctx_p, ctypes.c_int, _c_double_p, _c_i64_p],

@@ -50,6 +50,21 @@ class HipGP:
         check(self._lib.edrgp_set_data(self._ctx, dptr(X), dptr(y), X.shape[0], X.shape[1]))
         self.N, self.D = X.shape
 
+    def set_data_projected(self, W, Xbase=None, y=None):
+        """X = Xbase @ W on the device; Xbase / y are uploaded when given and stay resident otherwise."""
+        W = as_f64(W)
+        if Xbase is not None:
+            Xbase = as_f64(Xbase)
+            y = as_f64(np.ravel(y))
+            if Xbase.ndim != 2 or y.shape[0] != Xbase.shape[0] or W.shape[0] != Xbase.shape[1]:
+                raise ValueError("Xbase must be (N, Dbase), y (N,), W (Dbase, d)")
+            self._base_shape = Xbase.shape
+        elif getattr(self, "_base_shape", None) is None or W.shape[0] != self._base_shape[1]:
+            raise ValueError("no resident base rows matching W")
+        n, dbase = self._base_shape
+        check(self._lib.edrgp_set_data_projected(self._ctx, dptr(Xbase), dptr(y), n, dbase, dptr(W), W.shape[1]))
+        self.N, self.D = n, W.shape[1]
+
     def set_inducing(self, Z):
         Z = as_f64(Z)
         if Z.ndim != 2 or Z.shape[1] != self.D:
@@ -125,6 +140,14 @@ class HipGP:
         grad = np.empty((self.N, self.D)) if want_grad else None
         check(self._lib.edrgp_predict_train(self._ctx, dptr(mean), dptr(grad)))
         return mean, grad
+
+    def predict_train_gram(self, want_mean=False):
+        """J^T J (D x D) and the column sums of J = d mean / d x over the training rows, reduced on the device."""
+        mean = np.empty(self.N) if want_mean else None
+        gram = np.empty((self.D, self.D))
+        gsum = np.empty(self.D)
+        check(self._lib.edrgp_predict_train_gram(self._ctx, dptr(mean), dptr(gram), dptr(gsum)))
+        return mean, gram, gsum
 
     # -- parity / profiling accessors --------------------------------------
     def get(self, name, shape):

@@ -827,7 +827,16 @@ static int dense_eval(Ctx* c, bool need_grad, bool need_post, DenseOut* out) {
 }
 
 // Prediction on a device-resident block of inputs; outputs to host pointers.
-static int predict_rows(Ctx* c, const double* Xs_dev, int64_t Ns, double* mean_h, double* var_h, double* jac_h) {
+__global__ void fill_ones_kernel(double* __restrict__ p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 1.0;
+}
+
+// gram_h / gsum_h (optional): the D x D outer-product matrix J^T J of the posterior-mean gradients and
+// their column sums, accumulated on the device chunk by chunk -- what the EDR step and the candidate
+// sweep (BASELINE config 4) consume -- so the N x D gradient matrix need not cross PCIe.
+static int predict_rows(Ctx* c, const double* Xs_dev, int64_t Ns, double* mean_h, double* var_h, double* jac_h,
+                        double* gram_h = nullptr, double* gsum_h = nullptr) {
     if (!c->have_post) { set_error("no posterior: call *_posterior first"); return EDRGP_ERR_STATE; }
     const int D = c->D, Mp = c->P, Wd = 2 * D + 1;
     const KSpec ks = make_kspec(c);
@@ -843,16 +852,34 @@ static int predict_rows(Ctx* c, const double* Xs_dev, int64_t Ns, double* mean_h
     double* o_mean = o_jac + (size_t)chunk * D;
     double* o_var = o_mean + chunk;
     const double kdiag = var_sum(c);
+    const bool want_gram = (gram_h != nullptr);
+    double* d_gram = nullptr;
+    double* d_ones = nullptr;
+    if (want_gram) {
+        TRY(c->g2.reserve(((size_t)D * D + D + (size_t)chunk + 8) * sizeof(double)));
+        d_gram = c->g2.d();
+        d_ones = d_gram + (size_t)D * D + D;
+        hipLaunchKernelGGL(fill_ones_kernel, dim3((unsigned)((chunk + 255) / 256)), dim3(256), 0, c->stream, d_ones, chunk);
+    }
     for (int64_t r0 = 0; r0 < Ns; r0 += chunk) {
         const int64_t rows = std::min<int64_t>(chunk, Ns - r0);
         TRY(predict_chunk(c, ks, Xs_dev + (size_t)r0 * D, rows, Pp, Pt, Mp, c->wv.d(), c->winv.d(), kdiag,
                           c->Knm.d(), c->W.d(), GT, mean_h ? o_mean : nullptr, var_h ? o_var : nullptr,
-                          jac_h ? o_jac : nullptr));
+                          (jac_h || want_gram) ? o_jac : nullptr));
+        if (want_gram) {
+            TRY(gemm(c, true, false, D, D, (int)rows, 1.0, o_jac, D, o_jac, D, r0 > 0 ? 1.0 : 0.0, d_gram, D));
+            TRY(gemm(c, true, false, D, 1, (int)rows, 1.0, o_jac, D, d_ones, 1, r0 > 0 ? 1.0 : 0.0, d_gram + (size_t)D * D, 1));
+        }
         if (mean_h) HIP_TRY(hipMemcpyAsync(mean_h + r0, o_mean, rows * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         if (var_h) HIP_TRY(hipMemcpyAsync(var_h + r0, o_var, rows * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         if (jac_h)
             HIP_TRY(hipMemcpyAsync(jac_h + (size_t)r0 * D, o_jac, (size_t)rows * D * sizeof(double),
                                    hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    if (want_gram) {
+        HIP_TRY(hipMemcpyAsync(gram_h, d_gram, (size_t)D * D * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (gsum_h) HIP_TRY(hipMemcpyAsync(gsum_h, d_gram + (size_t)D * D, (size_t)D * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     return EDRGP_OK;
@@ -915,7 +942,7 @@ int edrgp_ctx_destroy(edrgp_ctx* ctx) {
     (void)hipStreamSynchronize(c->stream2);
     c->drain_events();
     if (c->comm) edrgp_comm_destroy(ctx);
-    DBuf* bufs[] = {&c->X, &c->y, &c->Z, &c->Xt, &c->Zt, &c->Xq, &c->g2, &c->Knm32, &c->T32, &c->S2f, &c->Xq32,
+    DBuf* bufs[] = {&c->Xbase, &c->X, &c->y, &c->Z, &c->Xt, &c->Zt, &c->Xq, &c->g2, &c->Knm32, &c->T32, &c->S2f, &c->Xq32,
                     &c->ks32_x, &c->ks32_z, &c->ks32_xn, &c->ks32_zn, &c->invl, &c->wv, &c->winv, &c->Knm, &c->W, &c->T, &c->slabs,
                     &c->bpart, &c->scal, &c->info, &c->gt_nm, &c->gt_mm, &c->panel, &c->trtri_ws, &c->dinv, &c->red};
     for (DBuf* b : bufs) b->release();
@@ -1007,6 +1034,53 @@ int edrgp_set_data(edrgp_ctx* ctx, const double* X, const double* y, int64_t N, 
     HIP_TRY(hipMemcpyAsync(&yy, c->scal.d() + SC_YY, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->yy_local = yy;
+    c->have_data = true;
+    return EDRGP_OK;
+}
+
+// Training inputs as a projection of resident base rows: X = Xbase W (N x d), computed on the device.
+// Xbase (N x Dbase) and y are uploaded when given and stay resident for later calls with Xbase == NULL
+// (candidate projections of the sweep / the EDR loop's X C^T, edrgp/base.py:459-517): a new candidate
+// costs the upload of W and one N x d x Dbase product instead of a host product and an N x d upload.
+int edrgp_set_data_projected(edrgp_ctx* ctx, const double* Xbase, const double* y, int64_t N, int Dbase,
+                             const double* W, int d) {
+    CTX(ctx);
+    if (!W || d <= 0 || d > EDRGP_MAX_DIM || Dbase <= 0 || N <= 0) { set_error("set_data_projected: bad shape"); return EDRGP_ERR_INVALID; }
+    if (Xbase != nullptr) {
+        if (!y) { set_error("set_data_projected: y is required with Xbase"); return EDRGP_ERR_INVALID; }
+        TRY(c->Xbase.reserve((size_t)N * Dbase * sizeof(double)));
+        TRY(c->y.reserve((size_t)N * sizeof(double)));
+        TRY(c->scal.reserve(SC_COUNT * sizeof(double)));
+        HIP_TRY(hipMemcpyAsync(c->Xbase.d(), Xbase, (size_t)N * Dbase * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->y.d(), y, (size_t)N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        TRY(sum_sq(c, c->y.d(), N, c->scal.d() + SC_YY));
+        double yy = 0.0;
+        HIP_TRY(hipMemcpyAsync(&yy, c->scal.d() + SC_YY, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->yy_local = yy;
+        c->base_N = N;
+        c->base_D = Dbase;
+    } else if (c->base_N != N || c->base_D != Dbase) {
+        set_error("set_data_projected: no resident base rows of shape %lld x %d", (long long)N, Dbase);
+        return EDRGP_ERR_STATE;
+    }
+    if (c->have_Z && c->D != d) c->have_Z = false;
+    if (c->have_kernel && c->D != d) c->have_kernel = false;
+    c->have_post = false;
+    TRY(c->X.reserve((size_t)N * d * sizeof(double)));
+    TRY(c->Xt.reserve((size_t)N * (2 * d + 1) * sizeof(double)));
+    TRY(c->Xq.reserve((size_t)N * 2 * d * sizeof(double)));
+    TRY(c->tmpvec[5].reserve((size_t)Dbase * d * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(c->tmpvec[5].d(), W, (size_t)Dbase * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (N > 0x7fffffffLL) { set_error("set_data_projected: N too large"); return EDRGP_ERR_INVALID; }
+    TRY(gemm(c, false, false, (int)N, d, Dbase, 1.0, c->Xbase.d(), Dbase, c->tmpvec[5].d(), d, 0.0, c->X.d(), d));
+    c->N = N;
+    c->D = d;
+    c->xq32_valid = false;
+    c->phi32_bad = false;
+    TRY(build_xtilde(c, c->X.d(), N, d, c->Xt.d()));
+    TRY(build_xq(c, c->X.d(), N, d, c->Xq.d()));
+    HIP_TRY(hipStreamSynchronize(c->stream));      // W is a borrowed host pointer
     c->have_data = true;
     return EDRGP_OK;
 }
@@ -1142,6 +1216,13 @@ int edrgp_predict_train(edrgp_ctx* ctx, double* mean, double* grad) {
     CTX(ctx);
     if (!c->have_data) { set_error("predict_train: no data"); return EDRGP_ERR_STATE; }
     return predict_rows(c, c->X.d(), c->N, mean, nullptr, grad);
+}
+
+int edrgp_predict_train_gram(edrgp_ctx* ctx, double* mean, double* gram, double* gsum) {
+    CTX(ctx);
+    if (!c->have_data) { set_error("predict_train_gram: no data"); return EDRGP_ERR_STATE; }
+    if (!gram) { set_error("predict_train_gram: gram is required"); return EDRGP_ERR_INVALID; }
+    return predict_rows(c, c->X.d(), c->N, mean, nullptr, nullptr, gram, gsum);
 }
 
 int edrgp_get(edrgp_ctx* ctx, int which, double* buf, int64_t cap) {

@@ -21,18 +21,23 @@ def length_scale_grid(d, n=16):
 
 
 def projection_sweep(X, y, Z_rows, projections, n_scales=16, kind="RBF", variance=1.0, noise=0.01,
-                     rank=0, world_size=1, device=None, want_gradients=False, hip=None):
+                     rank=0, world_size=1, device=None, want_gradients=False, hip=None, want_gram=False):
     """Evaluate the Titsias bound (and optionally the posterior-mean gradients at the
     training rows) for every (projection, length-scale) pair owned by this rank.
 
     X (N, D), y (N,) standardised; Z_rows: indices of the training rows used as inducing
     inputs (projected with each candidate); projections: list of (D, d_c) matrices.
     Returns a list of dicts: candidate, scale index, lengthscale, bound, and (if asked)
-    ``grad`` (N, d_c) and its back-projection ``grad @ W.T`` (N, D).
+    ``grad`` (N, d_c) and its back-projection ``grad @ W.T`` (N, D), or -- ``want_gram``, the
+    cheap form: the gradients never leave the device -- ``gram`` = grad^T grad (d_c, d_c),
+    ``gsum`` (d_c,) and the back-projected ``gram_full`` = W gram W^T (D, D), whose leading
+    eigenvectors are the EDR directions of that candidate.
     """
     own = hip is None
     h = HipGP(0 if device is None else device) if own else hip
     out = []
+    base_sent = False
+    X = np.ascontiguousarray(X, dtype=np.float64)
     try:
         for c, W in enumerate(projections):
             W = np.asarray(W, dtype=np.float64)
@@ -40,14 +45,19 @@ def projection_sweep(X, y, Z_rows, projections, n_scales=16, kind="RBF", varianc
             mine = [g for g in range(n_scales) if (c * n_scales + g) % world_size == rank]
             if not mine:
                 continue
-            Xp = np.ascontiguousarray(X @ W)
-            h.set_data(Xp, y)                       # one upload per candidate, reused for every scale
-            h.set_inducing(np.ascontiguousarray(Xp[Z_rows]))
+            # rows stay resident: a candidate uploads W only and projects on the device
+            h.set_data_projected(W, X if not base_sent else None, y if not base_sent else None)
+            base_sent = True
+            h.set_inducing(np.ascontiguousarray(X[Z_rows] @ W))
             for g in mine:
-                ls = np.full((1, Xp.shape[1]), scales[g])
+                ls = np.full((1, W.shape[1]), scales[g])
                 h.set_kernel([kind], [variance], ls, noise)
                 rec = {"candidate": c, "scale": g, "lengthscale": float(scales[g])}
                 rec["bound"] = h.sparse_posterior()
+                if want_gram:
+                    _, gram, gsum = h.predict_train_gram()
+                    rec["gram"], rec["gsum"] = gram, gsum
+                    rec["gram_full"] = W @ gram @ W.T
                 if want_gradients:
                     _, grad = h.predict_train(want_mean=False, want_grad=True)
                     rec["grad"] = grad

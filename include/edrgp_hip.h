@@ -95,6 +95,12 @@ int  edrgp_set_option(edrgp_ctx* ctx, const char* key, double value);
  * gp_model/base.py:87, Standardize at regression.py:48,124).  Copied to HBM
  * once and kept resident. */
 int  edrgp_set_data(edrgp_ctx* ctx, const double* X, const double* y, int64_t N, int D);
+/* Training inputs as a projection of resident base rows: X = Xbase W (N x d) computed on the
+ * device.  Xbase (N x Dbase) and y are uploaded when Xbase != NULL and stay resident for later
+ * calls with Xbase == NULL, y == NULL -- the candidate projections of BASELINE config 4 and the
+ * EDR loop's X C^T (edrgp/base.py:459-517; edrgp/edr.py:215-241 maps gradients back with W). */
+int  edrgp_set_data_projected(edrgp_ctx* ctx, const double* Xbase, const double* y, int64_t N,
+                              int Dbase, const double* W, int d);
 /* Inducing inputs Z (M x D): GPy SparseGPRegression's Z parameter
  * (regression.py:153-157).  Re-sent whenever the optimiser moves Z. */
 int  edrgp_set_inducing(edrgp_ctx* ctx, const double* Z, int M);
@@ -129,6 +135,12 @@ int  edrgp_predict_grad(edrgp_ctx* ctx, const double* Xs, int64_t Ns, double* gr
 /* Same as edrgp_predict + edrgp_predict_grad on the resident training X
  * (what EDR calls: edrgp/base.py:274 with X = training set); outputs host. */
 int  edrgp_predict_train(edrgp_ctx* ctx, double* mean, double* grad);
+/* The same pass over the training rows, reduced on the device: gram (D x D) = J^T J with
+ * J = d mean / d x (N x D), gsum (D, may be NULL) = column sums of J, mean (N, may be NULL).
+ * This is what the EDR step (SVD / PCA of the gradients, edrgp/utils.py:27-55 via
+ * edrgp/base.py:459-463) and the candidate sweep of BASELINE config 4 consume; the N x D
+ * gradient matrix stays in HBM. */
+int  edrgp_predict_train_gram(edrgp_ctx* ctx, double* mean, double* gram, double* gsum);
 
 /* debug / parity accessor */
 int  edrgp_get(edrgp_ctx* ctx, int which, double* buf, int64_t cap_elems);

@@ -38,3 +38,36 @@ def test_projection_sweep_matches_oracle_and_shards(hip):
     for part in parts:
         for p in part:
             assert p["bound"] == lookup[(p["candidate"], p["scale"])]
+
+
+def test_sweep_gram_and_device_projection(hip):
+    """The gradient outer-product matrix reduced on the device equals grad^T grad of the copied
+    gradients, its back-projection W G W^T equals grad_full^T grad_full, and data projected on the
+    device (edrgp_set_data_projected) gives the bound of the host-projected data."""
+    from edrgp_amd.sweep import projection_sweep
+    rng = np.random.default_rng(5)
+    N, D, M = 3000, 12, 64
+    X = rng.standard_normal((N, D))
+    y = np.tanh(X[:, 0] + 0.3 * X[:, 2]) + 0.05 * rng.standard_normal(N)
+    y = (y - y.mean()) / y.std()
+    projections = [np.linalg.qr(rng.standard_normal((D, D - c)))[0] for c in (0, 5, 11)]
+    Zrows = rng.permutation(N)[:M]
+    recs = projection_sweep(X, y, Zrows, projections, n_scales=3, want_gradients=True, want_gram=True, hip=hip)
+    assert len(recs) == 9
+    for rec in recs:
+        g = rec["grad"]
+        ref = g.T @ g
+        assert np.abs(rec["gram"] - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1e-300)
+        assert np.abs(rec["gsum"] - g.sum(0)).max() <= 1e-11 * max(np.abs(g).sum(0).max(), 1e-300)
+        full = rec["grad_full"].T @ rec["grad_full"]
+        assert np.abs(rec["gram_full"] - full).max() <= 1e-11 * max(np.abs(full).max(), 1e-300)
+    # device projection vs host projection of the same candidate
+    W = projections[1]
+    Xp = np.ascontiguousarray(X @ W)
+    hip.set_data(Xp, y)
+    hip.set_inducing(np.ascontiguousarray(Xp[Zrows]))
+    hip.set_kernel(["RBF"], [1.0], np.full((1, Xp.shape[1]), recs[4]["lengthscale"]), 0.01)
+    ref = hip.sparse_lml()
+    assert abs(recs[4]["bound"] - ref) <= 1e-10 * abs(ref)
+    with pytest.raises(ValueError):
+        hip.set_data_projected(np.zeros((D + 1, 2)))          # W does not match the resident base rows
