@@ -215,6 +215,7 @@ struct Ctx {
     int overlap = 3;                  // 0 none; 1 Kmm gradient term beside the gradient contraction;
                                       // 2 also phase 1 beside the row pass (stretches the Phi kernel);
                                       // 3 = 2 for bound-only evaluations, 1 for gradient evaluations
+    bool syrk_xmap = true;            // Phi: split-major workgroup -> XCD map (la_gemm.hip)
     bool chol_fused = true;           // Cholesky: panel + trailing update in one launch per step (la_chol.hip)
     bool rbf_epilogue = true;         // RBF: fused gradient epilogue takes h(r) = -k(r) from the resident K_nm
     bool fuse_grad = true;            // fused Q .* h epilogue of the gradient contraction (single-part kernels, D <= 32)

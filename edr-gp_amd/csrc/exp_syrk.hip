@@ -108,10 +108,90 @@ __global__ __launch_bounds__(256, 2) void syrk_direct_kernel(const double* __res
         }
 }
 
+// ---- variant 3: the production tiling (128x128 tile, BK = 16, 2x2 waves, [k][m] LDS images with row
+// stride 144 doubles, double-buffered) with LDS-DMA staging: one global_load_lds_dwordx4 wave-instruction
+// moves one k-row of one operand (128 doubles = 1 KB = 64 lanes x 16 B) straight into its padded LDS row.
+// No staging registers, no ds_write phase, no per-thread address arithmetic in the loop.
+constexpr int GBK = 16, GLD = 128 + 16;
+__global__ __launch_bounds__(256, 2) void syrk_glds_kernel(const double* __restrict__ K, int rows, int M, int ld,
+                                                           double* __restrict__ slabs, long long slabStride, int splits) {
+    __shared__ __attribute__((aligned(16))) double As[2][GBK * GLD];
+    __shared__ __attribute__((aligned(16))) double Bs[2][GBK * GLD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lq = lane >> 4;
+    int ti, tj;
+    tri_tile(xcd_remap(blockIdx.x, gridDim.x), ti, tj);
+    const int kt_total = rows / GBK;
+    const int kt_per = (kt_total + splits - 1) / splits;
+    const int kt0 = blockIdx.y * kt_per, kt1 = min(kt_total, kt0 + kt_per);
+
+    d4 acc[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] = d4{0.0, 0.0, 0.0, 0.0};
+
+    // this wave's four k-rows of each operand: rows wave, wave+4, wave+8, wave+12 of the k-tile
+    const char* ga = reinterpret_cast<const char*>(K + (size_t)kt0 * GBK * ld + ti * 128) + lane * 16;
+    const char* gb = reinterpret_cast<const char*>(K + (size_t)kt0 * GBK * ld + tj * 128) + lane * 16;
+    const size_t rowB = (size_t)ld * 8, tileB = (size_t)GBK * ld * 8;
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int kr = wave + 4 * q;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga + kr * rowB),
+                                             (__attribute__((address_space(3))) void*)(&As[buf][kr * GLD]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + kr * rowB),
+                                             (__attribute__((address_space(3))) void*)(&Bs[buf][kr * GLD]), 16, 0, 0);
+        }
+    };
+    if (kt0 < kt1) {
+        stage(0);
+        __syncthreads();                              // vmcnt(0) + barrier: tile kt0 is in LDS
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int buf = (kt - kt0) & 1;
+            if (kt + 1 < kt1) {
+                ga += tileB;
+                gb += tileB;
+                stage(buf ^ 1);
+            }
+            __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+            for (int kk = 0; kk < GBK / 4; ++kk) {
+                double a[4], b[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) a[x] = As[buf][(kk * 4 + lq) * GLD + wm * 64 + x * 16 + lr];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) b[x] = Bs[buf][(kk * 4 + lq) * GLD + wn * 64 + x * 16 + lr];
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 4; ++y)
+                        acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(2);
+            __syncthreads();                          // next tile landed (vmcnt(0)), everyone done with `buf`
+        }
+    }
+    double* C = slabs + (long long)blockIdx.y * slabStride;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            const int col = tj * 128 + wn * 64 + y * 16 + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = ti * 128 + wm * 64 + x * 16 + lq + 4 * r;
+                C[(size_t)row * M + col] = acc[x][y][r];
+            }
+        }
+}
+
 int syrk_variant(Ctx* c, const double* K, int rows, int M, int ld, int variant, int splits, double* Phi) {
     const int tm = M / 128;
     const long long nt = (long long)tm * (tm + 1) / 2;
-    if (splits <= 0) splits = (int)std::max<long long>(1, (8LL * c->num_cu) / nt);
+    if (splits <= 0) splits = (variant == 3) ? pick_syrk_splits(c, nt, rows / 16, rows, M, 128, 8) : (int)std::max<long long>(1, (8LL * c->num_cu) / nt);
     const long long slabStride = (long long)M * M;
     TRY(c->slabs.reserve((size_t)splits * slabStride * sizeof(double)));
     dim3 grid((unsigned)nt, (unsigned)splits);
@@ -119,6 +199,7 @@ int syrk_variant(Ctx* c, const double* K, int rows, int M, int ld, int variant, 
     unsigned long long* clk = static_cast<unsigned long long*>(c->red.p);
     if (variant == 1) hipLaunchKernelGGL((syrk_direct_kernel<2>), grid, dim3(256), 0, c->stream, K, rows, M, ld, c->slabs.d(), slabStride, splits, clk);
     else if (variant == 2) hipLaunchKernelGGL((syrk_direct_kernel<1>), grid, dim3(256), 0, c->stream, K, rows, M, ld, c->slabs.d(), slabStride, splits, clk);
+    else if (variant == 3) hipLaunchKernelGGL(syrk_glds_kernel, grid, dim3(256), 0, c->stream, K, rows, M, ld, c->slabs.d(), slabStride, splits);
     else { set_error("unknown syrk variant %d", variant); return EDRGP_ERR_INVALID; }
     HIP_TRY(hipGetLastError());
     if (Phi) TRY(slab_reduce_mirror(c, c->slabs.d(), splits, slabStride, M, Phi));

@@ -45,6 +45,7 @@ struct GemmArgs {
     FuseK fusek;                  // TAG 3 only
     int fuse_on;
     int dephase;        // 0 none; 1 s_setprio on odd wave slots; 2 half-tile start delay on odd wave slots
+    int xmap;           // 1: split-major XCD map (see the kernel)
     int kmode;          // triangular operands: bit0 k <= row tile end, bit1 k >= row tile start,
                         //                      bit2 k <= col tile end, bit3 k >= col tile start
 };
@@ -173,8 +174,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     // ---- tile id with an XCD-aware (bijective) remap: blocks b, b+8, ... share
     // an XCD (L2), give them consecutive tiles so they share operand panels.
     const int nt = gridDim.x;
-    int t;
-    {
+    int t, split = blockIdx.y;
+    if (g.xmap) {
+        // split-major XCD map (Phi): workgroups are dispatched x-fastest and dealt to the 8 XCDs round-robin;
+        // order them (split, tile) and give every XCD a contiguous eighth, so the workgroups running together
+        // on an XCD are the tiles of ONE row range: each K_nm row block is fetched once into that XCD's L2 and
+        // shared by all column panels, and each XCD reads ~1/8 of K_nm instead of all of it.
+        const int total = nt * (int)gridDim.y;
+        const int lin = (int)blockIdx.y * nt + (int)blockIdx.x;
+        const int q = total >> 3, r = total & 7, x = lin & 7, in = lin >> 3;
+        const int w = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + in;
+        split = w / nt;
+        t = w - split * nt;
+    } else {
         const int bid = blockIdx.x;
         const int q = nt >> 3, r = nt & 7, x = bid & 7, in = bid >> 3;
         t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + in;
@@ -199,12 +211,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 
     const double* A = g.A + (long long)z * g.strideA;
     const double* B = g.B + (long long)z * g.strideB;
-    double* C = g.C + (long long)z * g.strideC + (long long)blockIdx.y * g.slabStride;
+    double* C = g.C + (long long)z * g.strideC + (long long)split * g.slabStride;
 
     // ---- split-K range (in units of BK)
     const int kt_total = (Keff + BK - 1) / BK;
     const int kt_per = (kt_total + g.splits - 1) / g.splits;
-    int kt0 = blockIdx.y * kt_per;
+    int kt0 = split * kt_per;
     int kt1 = min(kt_total, kt0 + kt_per);
     if (g.kmode) {          // skip k-tiles where a triangular operand is identically zero
         int k_lo = 0, k_hi = Keff;
@@ -637,6 +649,7 @@ static int gemm_impl(Ctx* c, bool transA, bool transB, int M, int N, int K, doub
     g.splits = splits;
     g.tri = o.tri;
     g.kmode = o.kmode;
+    g.xmap = (o.tag == 1 || o.tag == 9) && o.tri && splits > 1 && o.batch == 1 && c->syrk_xmap;
     g.dephase = c->gemm_dephase;
     g.stamps = nullptr;
     g.fuse_on = 0;

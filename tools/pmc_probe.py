@@ -11,6 +11,8 @@ from edrgp_amd.backend import HipGP  # noqa: E402
 N, M, D = 100000, 2048, 32
 X, y, Z = bench.synthetic(N, D, M, seed=1000)
 h = HipGP(0)
+if len(sys.argv) > 2:
+    h.set_option("syrk_xmap", int(sys.argv[2]))
 h.set_data(X, y)
 h.set_inducing(Z)
 h.set_kernel(["RBF"], [1.0], np.full((1, D), np.sqrt(D)), 0.01)
