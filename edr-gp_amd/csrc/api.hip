@@ -625,7 +625,9 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
             TRY(kernel_matrix(c, ks, c->X.d() + (size_t)r0 * D, rows, c->Z.d(), M, c->Knm.d(), M, 0, 0.0, nullptr,
                               nullptr));
         }
-        const bool fused = (np == 1) && (D <= 32) && c->fuse_grad;
+        // the distance-recomputing epilogue stages D <= 32 features; the RBF epilogue reads k from K_nm: any D
+        const bool fused = (np == 1) && c->fuse_grad &&
+                           (D <= 32 || (c->kind[0] == EDRGP_KERN_RBF && c->rbf_epilogue));
         if (fused) {
             // T = (K_nm S2 + beta y wv^T) .* h(r) and the d/dvariance partials straight out of
             // the contraction's epilogue: no W round trip, no separate element-wise pass

@@ -52,6 +52,9 @@ CASES = [
     (700, 100, 6, ["RBF"], [dict(variance=0.9, lengthscale=[1.5, 2.0, 2.5, 3.0, 3.5, 4.0], ARD=True)], 0.05),
     (600, 70, 5, ["RBF", "Matern52"], [dict(variance=0.6, lengthscale=2.0), dict(variance=0.3, lengthscale=1.2)], 0.05),
     (3000, 200, 16, ["RBF"], [dict(variance=1.0, lengthscale=4.0)], 0.01),
+    # D > 32: RBF keeps the fused gradient epilogue (k read back from K_nm), Matern takes the unfused path
+    (1500, 130, 40, ["RBF"], [dict(variance=1.2, lengthscale=6.0)], 0.05),
+    (1500, 130, 40, ["Matern52"], [dict(variance=1.2, lengthscale=6.0)], 0.05),
 ]
 
 
