@@ -412,7 +412,9 @@ static int potrf_lower_fused(Ctx* c, double* A, int n, int lda, int* info_dev) {
 }
 
 int potrf_lower(Ctx* c, double* A, int n, int lda, int* info_dev) {
-    if (c->chol_fused && n > NB) return potrf_lower_fused(c, A, n, lda, info_dev);
+    // one launch per step wins while the steps are latency-bound (M = 2048: -3 % on the O(M^3) phase); its
+    // recomputed panel tiles triple the MFMA work, which costs +13 % at n = 4096 and +28 % at 8192
+    if (c->chol_fused && n > NB && n <= 3072) return potrf_lower_fused(c, A, n, lda, info_dev);
     HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), c->stream));
     if (c->dinv.bytes < (size_t)NB * NB * sizeof(double)) {
         TRY(c->dinv.reserve((size_t)NB * NB * sizeof(double)));
