@@ -195,7 +195,9 @@ static GemmOpts kopt(int kmode, int tri = 0, int tag = 0) {
     o.tag = tag;
     // zero-skipping makes the k-range depend on the tile: with one 128x128 tile per CU the
     // longest tile sets the time, 64x64 tiles (4 per CU, mixed lengths) balance it
-    if (kmode != 0 && tag == 0) o.force_tile = g_tri_tile;
+    // (at M >= 4096 there are >= 1024 tiles of 128x128: the larger tile's MFMA efficiency wins again --
+    //  gemm_impl resolves force_tile = -1 by the tile count)
+    if (kmode != 0 && tag == 0) { o.force_tile = -1; o.small_tile = g_tri_tile; }
     return o;
 }
 

@@ -105,7 +105,8 @@ struct GemmOpts {
     int limK_base = 0, limK_stride = 0;      // K_eff(z) likewise
     int tri = 0;                             // 1: only tiles with ti >= tj (M == N)
     int kmode = 0;                           // zero-skipping for triangular operands, see K_* below
-    int force_tile = 0;                      // 64 or 128; 0 = heuristic
+    int force_tile = 0;                      // 64 or 128; 0 = heuristic; -1 = 128 if that gives >= 1024 tiles, else small_tile
+    int small_tile = 64;
 };
 
 // k-range restrictions (GemmOpts::kmode) for triangular operands

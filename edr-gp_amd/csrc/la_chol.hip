@@ -45,7 +45,8 @@ __global__ __launch_bounds__(256) void diag_block_kernel(double* __restrict__ Ab
                                                         double* __restrict__ inv_out, int ldi,
                                                         int* __restrict__ info,
                                                         unsigned long long* __restrict__ stamps,
-                                                        double* __restrict__ Lbase = nullptr, int ldlo = 0) {
+                                                        double* __restrict__ Lbase = nullptr, int ldlo = 0,
+                                                        int info_off = 0) {
     __shared__ double Lt[NB][NB + 1];      // Lt[k][i] = L[i][k]
     __shared__ double Tl[4][16][17];       // inverses of the 16x16 diagonal blocks, row-major
     __shared__ double rdiag[NB];           // 1 / L[i][i]
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void diag_block_kernel(double* __restrict__ Ab
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const double p = readlane_f64(a[j], j);
-                if (!(p > 0.0) && bad == 0) bad = j0 + j + 1;
+                if (!(p > 0.0) && bad == 0) bad = info_off + j0 + j + 1;
                 // 1/sqrt(p): v_rsq_f64 + two Newton steps  y <- y (1.5 - 0.5 p y^2)
                 const double hp = 0.5 * p;
                 double y = __builtin_amdgcn_rsq(p);
@@ -387,8 +388,9 @@ __global__ void take_lower_kernel(double* __restrict__ A, int lda, const double*
 
 // Fused-step variant of potrf_lower (same contract): the factor is assembled in the panel workspace and
 // copied back, A is the work matrix of the trailing updates.
-static int potrf_lower_fused(Ctx* c, double* A, int n, int lda, int* info_dev) {
-    HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), c->stream));
+static int potrf_lower_fused(Ctx* c, double* A, int n, int lda, int* info_dev, bool reset_info = true,
+                             int info_off = 0) {
+    if (reset_info) HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), c->stream));
     if (c->dinv.bytes < (size_t)NB * NB * sizeof(double)) {
         TRY(c->dinv.reserve((size_t)NB * NB * sizeof(double)));
         HIP_TRY(hipMemsetAsync(c->dinv.d(), 0, (size_t)NB * NB * sizeof(double), c->stream));
@@ -399,7 +401,7 @@ static int potrf_lower_fused(Ctx* c, double* A, int n, int lda, int* info_dev) {
     const int nblk = (n + NB - 1) / NB;
     for (int b = 0; b < nblk; ++b) {
         hipLaunchKernelGGL(diag_block_kernel<true>, dim3(1), dim3(256), 0, c->stream, A, lda, n, b, Dinv,
-                           (double*)nullptr, 0, info_dev, (unsigned long long*)nullptr, Lw, n);
+                           (double*)nullptr, 0, info_dev, (unsigned long long*)nullptr, Lw, n, info_off);
         const int r = nblk - b - 1;
         if (r > 0)
             hipLaunchKernelGGL(chol_step_kernel, dim3((unsigned)(r * (r + 1) / 2)), dim3(256), 0, c->stream, A, lda, Lw, n,

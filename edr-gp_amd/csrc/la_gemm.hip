@@ -636,6 +636,10 @@ static int gemm_impl(Ctx* c, bool transA, bool transB, int M, int N, int K, doub
                      const GemmOpts& o, int splits, double* slab, long long slabStride, int slab_ld) {
     if (M <= 0 || N <= 0) return EDRGP_OK;
     int tile = o.force_tile;
+    if (tile < 0) {
+        const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * o.batch / (o.tri ? 2 : 1);
+        tile = (t128 >= 1024) ? 128 : o.small_tile;
+    }
     if (tile == 0) {
         const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * o.batch * splits;
         tile = (M >= 128 && N >= 128 && t128 >= 96) ? 128 : 64;
@@ -698,7 +702,7 @@ int gemm(Ctx* c, bool transA, bool transB, int M, int N, int K, double alpha, co
     // split-K only for long-K, small-output, unbatched products (e.g. T^T [X|1|X^2])
     int splits = 1;
     if (o.batch == 1 && !o.tri) {
-        const int tile = (o.force_tile ? o.force_tile : 64);
+        const int tile = (o.force_tile > 0 ? o.force_tile : 64);
         const long long nt = (long long)((M + tile - 1) / tile) * ((N + tile - 1) / tile);
         const int kt = (K + BK - 1) / BK;
         if (nt < 256 && kt >= 256) {
@@ -710,7 +714,7 @@ int gemm(Ctx* c, bool transA, bool transB, int M, int N, int K, double alpha, co
         const long long slabStride = (long long)M * N;
         TRY(c->slabs.reserve((size_t)splits * slabStride * sizeof(double)));
         GemmOpts o2 = o;
-        if (!o2.force_tile) o2.force_tile = 64;
+        if (o2.force_tile <= 0) o2.force_tile = 64;
         TRY(gemm_impl(c, transA, transB, M, N, K, 1.0, A, lda, B, ldb, 0.0, nullptr, 0, o2, splits,
                       c->slabs.d(), slabStride, N));
         dim3 blk(64, 4), grd((N + 63) / 64, (M + 3) / 4);

@@ -83,6 +83,21 @@ def test_potrf(hip, n):
     assert rel(L @ L.T, A) < 1e-13
 
 
+@pytest.mark.parametrize("n", [3100, 3584, 4100])
+def test_potrf_large(hip, n):
+    """n > 3072: the two-launch-per-step path (the fused step kernel is used up to 3072)"""
+    A = _spd(n, n, cond=1e3)
+    L, info = hip.dbg_potrf(A)
+    assert info == 0
+    ref = np.linalg.cholesky(A)
+    assert np.array_equal(np.triu(L, 1), np.zeros_like(L))
+    assert rel(L, ref) < 1e-11
+    B = A.copy()
+    B[3090, 3090] = -1.0
+    _, info = hip.dbg_potrf(B)
+    assert info == 3091
+
+
 def test_potrf_reports_failure(hip):
     A = _spd(130, 3)
     A[100, 100] = -1.0
