@@ -163,3 +163,22 @@ def test_calibration_runs(hip):
     tf, bw = hip.calib()
     print("fp64 MFMA issue rate: %.1f TFLOP/s; HBM copy: %.0f GB/s" % (tf, bw))
     assert tf > 10.0 and bw > 1000.0
+
+
+def test_covariance_exp_against_libm(hip):
+    """The covariance epilogues use their own exp for non-positive arguments (kfun.h): K(X, X2) for RBF /
+    Matern must agree with the oracle's libm-based values over the useful range.  Both sides form r^2 as
+    |x|^2 + |z|^2 - 2 x.z (GPy's formula), whose rounding error ~eps (|x|^2 + |z|^2) <= 1e-13 here becomes a
+    relative error of the covariance; the exp itself contributes ~1e-16."""
+    from oracle import gp_oracle as go
+    rng = np.random.default_rng(11)
+    X = rng.standard_normal((300, 3)) * np.array([0.01, 1.0, 6.0])      # r^2 from ~0 to a few hundred
+    X2 = rng.standard_normal((200, 3)) * np.array([0.01, 1.0, 6.0])
+    for kind in ("RBF", "Matern32", "Matern52"):
+        kern = go.make_kernel([kind], 3, [dict(variance=1.7, lengthscale=0.9)])
+        hip.set_data(X, np.zeros(300))
+        hip.set_kernel([kind], [1.7], np.full((1, 3), 0.9), 0.1)
+        K = hip.dbg_kernel_matrix(X, X2)
+        ref = kern.K(X, X2)
+        assert ref.min() < 1e-20 and ref.max() > 0.1
+        assert np.abs(K / ref - 1.0).max() < 3e-13
