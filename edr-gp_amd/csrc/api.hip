@@ -992,6 +992,8 @@ int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
     else if (!std::strcmp(key, "fuse_grad")) c->fuse_grad = (value != 0.0);
     else if (!std::strcmp(key, "tri_tile")) g_tri_tile = (int)value;
     else if (!std::strcmp(key, "mfma_kbuild")) c->mfma_kbuild = (value != 0.0);
+    else if (!std::strcmp(key, "kbuild_dbg")) c->kbuild_dbg = (int)value;
+    else if (!std::strcmp(key, "kbuild_tile")) c->kbuild_tile = (int)value;
     else if (!std::strcmp(key, "rbf_epilogue")) c->rbf_epilogue = (value != 0.0);
     else if (!std::strcmp(key, "chol_fused")) c->chol_fused = (value != 0.0);
     else if (!std::strcmp(key, "syrk_xmap")) c->syrk_xmap = (value != 0.0);

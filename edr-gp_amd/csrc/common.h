@@ -93,6 +93,7 @@ struct FuseK {
     double* bpart;          // tiles_m x N partial sums of K^T y (when y)
     double var, jitter;
     int kind, same;
+    int dbg;                // diagnostic: 1 no exp, 2 no store
 };
 
 struct GemmOpts {
@@ -213,6 +214,8 @@ struct Ctx {
     DBuf red2, slabs2;                    // scratch used while launching on the side stream
     DBuf ks_x, ks_z, ks_xn, ks_zn, ks_x2, ks_xn2;   // scaled inputs and squared norms for the MFMA kernel build
     bool mfma_kbuild = true;
+    int kbuild_dbg = 0;
+    int kbuild_tile = 64;                // tile of the MFMA kernel build (64 or 128)
     int overlap = 3;                  // 0 none; 1 Kmm gradient term beside the gradient contraction;
                                       // 2 also phase 1 beside the row pass (stretches the Phi kernel);
                                       // 3 = 2 for bound-only evaluations, 1 for gradient evaluations

@@ -357,10 +357,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                     const bool diag = f.same && (row == col);
                     if (diag) r2 = 0.0;
                     double Kv, hv;
-                    edrgp_kfun(f.kind, f.var, r2, Kv, hv);
+                    if (f.dbg & 1) { Kv = r2; hv = 0.0; } else edrgp_kfun(f.kind, f.var, r2, Kv, hv);
                     if (diag) Kv += f.jitter;
                     if (rok && col < g.N) {
-                        C[(size_t)row * g.ldc + col] = Kv;
+                        if (!(f.dbg & 2) || Kv == 12345.678) C[(size_t)row * g.ldc + col] = Kv;
                         bsum[y] = fma(Kv, yr, bsum[y]);
                     }
                 }

@@ -624,7 +624,7 @@ int kernel_matrix32(Ctx* c, const KSpec& ks, const double* X, int64_t rows, cons
     float* zn = static_cast<float*>(c->ks32_zn.p);
     TRY(scale_norm32(c, X, rows, D, ks.invl, xs, xn));
     TRY(scale_norm32(c, Z, M, D, ks.invl, zs, zn));
-    const int tile = (rows >= 128 && M >= 128) ? 128 : 64;
+    const int tile = (c->kbuild_tile == 128 && rows >= 128 && M >= 128) ? 128 : 64;     // see kernel_matrix_mfma
     const int tiles_m = (int)((rows + tile - 1) / tile);
     Fuse32K f;
     f.xn = xn; f.zn = zn; f.y = y; f.bpart = nullptr;
