@@ -3,7 +3,7 @@ needs minutes there): additivity of the row statistics over row blocks, chunking
 invariance, row-permutation invariance, central finite differences of the bound against
 the analytic gradients, and finite differences of the posterior mean against
 predict_gradient.  Configs: Cm (N=100k, M=2048, D=32, RBF) and C2 (N=100k, M=1024, D=16, RBF),
-C3's per-GPU shard shape with Matern-5/2 (N=125k, M=2048, D=32)."""
+C3's per-GPU shard shape with Matern-5/2 (N=125k, M=2048, D=32) and C3 whole (N=1M) on one device."""
 import numpy as np
 import pytest
 
@@ -19,7 +19,9 @@ def synthetic(N, D, M, seed):
     return X, y, Z
 
 
-CONFIGS = [("Cm", 100000, 2048, 32, "RBF"), ("C2", 100000, 1024, 16, "RBF"), ("C3-shard", 125000, 2048, 32, "Matern52")]
+CONFIGS = [("Cm", 100000, 2048, 32, "RBF"), ("C2", 100000, 1024, 16, "RBF"), ("C3-shard", 125000, 2048, 32, "Matern52"),
+           # config 3 whole on one device: 1M rows = 8 chunks of K_nm (2.1 GB each), nothing leaves HBM
+           ("C3-1M-rows", 1000000, 2048, 32, "Matern52")]
 
 
 @pytest.mark.parametrize("name,N,M,D,kind", CONFIGS, ids=[c[0] for c in CONFIGS])

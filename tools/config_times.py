@@ -16,7 +16,8 @@ def timeit(f, n=5):
     return (time.perf_counter() - t0) / n * 1e3
 
 for name, N, M, D, kind in [("C2", 100000, 1024, 16, "RBF"), ("Cm", 100000, 2048, 32, "RBF"),
-                            ("C3 shard (1/8 of 1M rows)", 125000, 2048, 32, "Matern52")]:
+                            ("C3 shard (1/8 of 1M rows)", 125000, 2048, 32, "Matern52"),
+                            ("C3 whole on one GPU", 1000000, 2048, 32, "Matern52")]:
     X, y, Z = bench.synthetic(N, D, M, seed=7)
     h.set_data(X, y); h.set_inducing(Z)
     h.set_kernel([kind], [1.0], np.full((1, D), np.sqrt(D)), 0.01)
