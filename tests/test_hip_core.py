@@ -209,3 +209,26 @@ def test_dense_lml_gradients_predict(hip, N, D, kinds, opts, noise):
     assert rel(mu, mu_ref[:, 0]) < 1e-8
     assert np.abs(var - var_ref[:, 0]).max() < 1e-8 * max(1.0, np.abs(var_ref).max())
     assert rel(hip.predict_grad(Xs), jac_ref) < 1e-8
+
+
+def test_bitwise_reproducible_across_overlap_modes(hip):
+    """Fixed-order reductions, no float atomics: the same evaluation gives the same bits on every repeat,
+    whichever side-stream overlap policy schedules it."""
+    X, y, Z = go.synthetic_problem(20000, 16, 512, seed=4)
+    hip.set_data(X, y)
+    ref = {}
+    try:
+        for i in range(24):
+            s = 1.0 + 1e-3 * (i % 3)
+            hip.set_option("overlap", (3, 0, 2, 1)[i % 4])
+            hip.set_inducing(Z)
+            hip.set_kernel(["RBF"], [s], np.full((1, 16), 4.0 * s), 0.01 * s)
+            out = hip.sparse_lml_grad() if i % 2 else (hip.sparse_lml(),)
+            key = (i % 3, len(out))
+            if key in ref:
+                for u, v in zip(ref[key], out):
+                    assert np.array_equal(np.asarray(u), np.asarray(v)), (i, key)
+            else:
+                ref[key] = out
+    finally:
+        hip.set_option("overlap", 3)
