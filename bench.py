@@ -72,9 +72,18 @@ def cpu_baseline(N_sample, M, D, kind, iters):
     """The CPU path timed beside the GPU one: the oracle (GPy's LAPACK/BLAS call
     sequence restated in numpy/scipy) on a bounded row sample, all host cores."""
     from oracle import gp_oracle as go
+    from edrgp_amd.utils import effective_cpus
     X, y, Z = synthetic(N_sample, D, M, seed=123)
     kern = go.make_kernel([kind], D, [dict(variance=1.0, lengthscale=np.sqrt(D))])
     Y = y[:, None]
+    # BLAS threads = the cores the process may really use (affinity capped by the cgroup quota): an
+    # oversubscribed pool (one thread per visible core of the host) would only slow the CPU path down
+    _cpu_threads = effective_cpus()
+    try:
+        from threadpoolctl import threadpool_limits
+        _limit = threadpool_limits(limits=_cpu_threads)
+    except Exception:
+        _limit = None
     t0 = time.perf_counter()
     inf = go.vardtc_inference(kern, X, Z, 0.01, Y)
     go.sparse_gradients(kern, X, Z, inf)
@@ -86,15 +95,9 @@ def cpu_baseline(N_sample, M, D, kind, iters):
     go.raw_predict(kern, X, Z, inf["woodbury_vector"], inf["woodbury_inv"])
     go.predictive_gradients_mean(kern, X, Z, inf["woodbury_vector"])
     t_pred = time.perf_counter() - t0
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        threads = os.cpu_count() or 1
-    try:
-        threads = min(threads, len(os.sched_getaffinity(0)))      # BLAS threads that can actually run
-    except AttributeError:
-        pass
+    threads = _cpu_threads
+    if _limit is not None:
+        _limit.restore_original_limits()
     step_time = iters * t_eval + t_lml + t_pred
     return {
         "value": N_sample / step_time, "unit": "points/s", "cores": int(threads), "kind": "port",

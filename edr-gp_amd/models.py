@@ -318,8 +318,10 @@ class _GPModel:
         if kwargs.get("bfgs_factor") is not None:
             opt_dict["factr"] = kwargs["bfgs_factor"]
         self._fail_count = 0
-        x_opt, f_opt, info = _sciopt.fmin_l_bfgs_b(self._objective_grads, x0, maxfun=int(max_iters),
-                                                   maxiter=int(max_iters), **opt_dict)
+        from .utils import host_threads
+        with host_threads():         # keep the host BLAS pool small while the device does the work
+            x_opt, f_opt, info = _sciopt.fmin_l_bfgs_b(self._objective_grads, x0, maxfun=int(max_iters),
+                                                       maxiter=int(max_iters), **opt_dict)
         self.optimizer_array = x_opt
         status = {0: "Converged", 1: "Maximum number of f evaluations reached"}.get(info["warnflag"], info.get("task", "Error"))
         run = OptimizationResult(np.array(x_opt), float(f_opt), info["funcalls"], status)
