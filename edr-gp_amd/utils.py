@@ -52,7 +52,10 @@ class SVDTransformer(BaseEstimator, TransformerMixin):
 
     def fit(self, X, y=None):
         Xc = check_array(X, copy=True)
-        _, S, Vh = np.linalg.svd(Xc)
+        # thin SVD: only S and V^T are used.  (The reference calls np.linalg.svd with full_matrices=True,
+        # edrgp/utils.py:140, which also builds the n_samples x n_samples U: 20 GB and 13 s per call at
+        # 50 000 gradient rows; S and V^T are the same.)
+        _, S, Vh = np.linalg.svd(Xc, full_matrices=False)
         var = S ** 2
         ratio = var / var.sum()
         k = Xc.shape[1]
