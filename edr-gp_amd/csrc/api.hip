@@ -430,6 +430,7 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
     }
     const double pr = h_sc[SC_DIAGMAX] / h_sc[SC_DIAGMIN];
     const double dmin_lm = h_sc[SC_DIAGMIN];
+    c->last_pivot_ratio2 = pr * pr;
     f32 = want32 && !c->phi32_bad && (pr * pr <= c->f32_ratio_max);
     const bool stable64 = (c->stats_mode == 2) || (c->stats_mode == 0 && pr * pr > c->pivot_ratio_max);
     bool stable = !f32 && stable64;
@@ -1265,6 +1266,7 @@ int edrgp_get(edrgp_ctx* ctx, int which, double* buf, int64_t cap) {
         case EDRGP_GET_MODE:
             buf[0] = (double)c->last_mode;
             if (cap >= 2) buf[1] = c->f32_rho;      // last fp32 guard estimate (0 if the fp32 pass never ran)
+            if (cap >= 3) buf[2] = c->last_pivot_ratio2;   // (max / min diag Lm)^2 of the last evaluation
             return EDRGP_OK;
         default: set_error("edrgp_get: unknown selector %d", which); return EDRGP_ERR_INVALID;
     }

@@ -1,0 +1,18 @@
+"""Random-shape parity sweep against the CPU oracle through the C ABI: ragged N / M / D (1..44 features,
+1..199 inducing inputs), single and sum kernels of the three kinds, tiny row chunks, automatic and
+stable statistics (tools/fuzz.py holds the generator and the conditioning-aware tolerances)."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+@pytest.mark.parametrize("seed", [0, 7])
+def test_random_shapes_match_oracle(hip, seed):
+    import fuzz
+    failing = fuzz.run(hip, seed=seed, n_cases=50, modes=(0, 0, 2), verbose=True)
+    assert failing == []
