@@ -16,3 +16,9 @@ def test_random_shapes_match_oracle(hip, seed):
     import fuzz
     failing = fuzz.run(hip, seed=seed, n_cases=50, modes=(0, 0, 2), verbose=True)
     assert failing == []
+
+
+def test_random_shapes_dense_and_gradient_gram(hip):
+    """Dense exact GP (bound, gradients, predictions) and the device-side J^T J on random shapes."""
+    import fuzz_dense
+    assert fuzz_dense.run(hip, seed=3, n_cases=30, verbose=True) == []
