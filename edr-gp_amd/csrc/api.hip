@@ -348,13 +348,14 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
     // precision 32 asks for the fp32 row pass; it is used while the Gram form is safe in fp32
     // (error ~ eps32 cond(Kmm), judged by the pivot-ratio proxy after phase 1), otherwise this
     // evaluation falls back to the fp64 row pass (last_mode: 1 gram fp64, 2 stable fp64, 3 gram fp32)
-    //   Phi in fp32 (f32): fast attempt, kept only if the a-posteriori guard below accepts it; a rejected
-    //     attempt is remembered (phi32_bad) until the data, Z or the precision change.
+    //   Phi in fp32 (f32): opt-in ("f32_phi" = 1; the bound is then only 1e-4..1e-3 accurate): attempted, kept only
+    //     if the a-posteriori guard below accepts it; a rejected attempt is remembered (phi32_bad) until the
+    //     data, Z or the precision change.  Default: Phi always from the fp64 row pass, the bound is exact.
     //   gradient contraction in fp32 (g32): always -- its rounding reaches the gradients only, never
     //     the positive definiteness of I + A.
     const bool want32 = (c->precision == 32) && (np == 1);
-    const bool g32 = want32 && need_grad && D <= 64 && M >= 128 && std::min<int64_t>(chunk, N) >= 128;
-    bool f32 = want32 && !c->phi32_bad;
+    bool g32 = want32 && need_grad && D <= 64;      // and a Kmm conditioned for the Gram form, decided after phase 1
+    bool f32 = want32 && c->f32_phi && !c->phi32_bad;
     bool k32_resident = false;
     auto phase2 = [&](bool stable) -> int {
         if (f32) {
@@ -431,8 +432,11 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
     const double pr = h_sc[SC_DIAGMAX] / h_sc[SC_DIAGMIN];
     const double dmin_lm = h_sc[SC_DIAGMIN];
     c->last_pivot_ratio2 = pr * pr;
-    f32 = want32 && !c->phi32_bad && (pr * pr <= c->f32_ratio_max);
+    f32 = want32 && c->f32_phi && !c->phi32_bad && (pr * pr <= c->f32_ratio_max);
     const bool stable64 = (c->stats_mode == 2) || (c->stats_mode == 0 && pr * pr > c->pivot_ratio_max);
+    // K_nm S2 in fp32 cancels catastrophically once Kmm is ill conditioned (S2 carries Kmm^-1): the fp32
+    // gradient contraction is used only where the Gram form itself is considered safe
+    if (stable64 || pr * pr > c->pivot_ratio_max) g32 = false;
     bool stable = !f32 && stable64;
     c->last_mode = f32 ? 3 : (stable ? 2 : 1);
     tr.mark("phase1 (+queued phase2)");
@@ -1006,6 +1010,7 @@ int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
     }
     else if (!std::strcmp(key, "f32_ratio_max")) c->f32_ratio_max = value;
     else if (!std::strcmp(key, "f32_guard")) c->f32_guard = value;
+    else if (!std::strcmp(key, "f32_phi")) { c->f32_phi = (value != 0.0); c->phi32_bad = false; }
     else if (!std::strcmp(key, "precision")) {
         // 64 (default): fp64 throughout.  32: the N-proportional row pass in fp32 (la_gemm32.hip)
         if ((int)value != 32 && (int)value != 64) { set_error("precision must be 32 or 64"); return EDRGP_ERR_INVALID; }

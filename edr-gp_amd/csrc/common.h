@@ -253,6 +253,7 @@ struct Ctx {
     double f32_ratio_max = 1e4;       // fp32 Gram form while (max/min diag Lm)^2 <= this, else the fp64 row pass
     DBuf Knm32, T32, S2f, Xq32, ks32_x, ks32_z, ks32_xn, ks32_zn;
     bool xq32_valid = false;
+    bool f32_phi = false;             // also try Phi in fp32 (guarded); default: fp32 only in the gradient contraction
     bool phi32_bad = false;           // the guard rejected the fp32 Phi for the current data: use the fp64 row pass
 
     // options

@@ -642,8 +642,8 @@ int kernel_matrix32(Ctx* c, const KSpec& ks, const double* X, int64_t rows, cons
 int grad_contract32(Ctx* c, const KSpec& ks, const float* K32, int64_t rows, int M, const float* S2f, const double* y,
                     const double* wv, double ycoef, float* T32, double* dvar_accum, double* cs) {
     const int D = ks.D;
-    if (ks.nparts != 1 || D > 64 || M < 128 || rows < 128) {
-        set_error("fp32 gradient path: single-part kernel, D <= 64, M >= 128 and >= 128 rows per chunk");
+    if (ks.nparts != 1 || D > 64) {
+        set_error("fp32 gradient path: single-part kernel, D <= 64");
         return EDRGP_ERR_INVALID;
     }
     const int tiles_m = (int)((rows + 127) / 128), tiles_n = (M + 127) / 128;

@@ -47,9 +47,8 @@ class SparseGaussianProcessRegressor(RegressorMixin, _BaseGP):
         ``num_inducing`` random training rows (global numpy RNG, as GPy does).
     num_inducing : int, default 10 (ignored when Z is given).
     X_variance : must be None.
-    precision : 'fp64' (default) or 'fp32' -- an addition to the reference signature.  'fp32' stores
-        K_nm and runs the gradient contraction on the fp32 MFMA (BASELINE config 5); the bound itself
-        uses the fp32 Gram matrix only when an a-posteriori check accepts it, otherwise fp64.
+    precision : 'fp64' (default) or 'fp32' -- an addition to the reference signature.  'fp32' runs the
+        gradient contraction of the native path on the fp32 MFMA (BASELINE config 5); the bound stays fp64.
     """
 
     def __init__(self, kernels=None, kernel_options=None, Z=None, num_inducing=10, Y_metadata=None,

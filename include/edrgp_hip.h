@@ -84,11 +84,12 @@ int  edrgp_sync(edrgp_ctx* ctx);
  * 1 Gram form Phi = K_mn K_nm, 2 stable form via K_nm Lm^-T), "pivot_ratio_max",
  * "overlap" (side-stream use: 0 none, 1 the Kmm gradient term beside the gradient contraction,
  * 2 also the Kmm Cholesky beside the row pass, 3 (default) = 2 for bound-only and 1 for
- * gradient evaluations), "precision" (64 default; 32 = BASELINE config 5: K_nm, the Phi
- * contraction and the gradient contraction stored / multiplied in fp32 on the fp32 MFMA,
- * slab sums and every M x M object fp64; used for single-part kernels (D <= 64 for gradients)
- * while the Gram form is safe in fp32, (max/min diag Lm)^2 <= "f32_ratio_max" (default 1e4),
- * otherwise the evaluation runs the fp64 row pass; EDRGP_GET_MODE reports 3 when fp32 ran) */
+ * gradient evaluations), "precision" (64 default; 32 = BASELINE config 5: K_nm stored in fp32 and the
+ * gradient contraction T = (K_nm S2 + ..) .* h(r), T^T [X | X.^2] on the fp32 MFMA with fp64 slab sums,
+ * for single-part kernels with D <= 64 while Kmm is conditioned for the Gram form; the bound itself stays
+ * fp64.  "f32_phi" = 1 additionally tries the Gram matrix Phi in fp32 and keeps it only if the
+ * factorisation of I + A succeeds without jitter and an error estimate stays below "f32_guard"
+ * (EDRGP_GET_MODE reports 3 then; the bound is 1e-4..1e-3 accurate in that mode)) */
 int  edrgp_set_option(edrgp_ctx* ctx, const char* key, double value);
 
 /* Training data (already validated / normalised by the host: check_X_y at

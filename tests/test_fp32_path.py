@@ -2,10 +2,10 @@
 
 Tolerances are the ones the path achieves against the fp64 CPU oracle and are written here:
 the fp32 MFMA is an exact k-ordered fmaf chain, the slabs are summed in fp64, every M x M
-object is fp64.  With the fp32 Gram matrix (mode 3):   bound 1e-4 rel, hyper-parameter
-gradients 2e-3, dZ 3e-2 (max-norm relative), posterior mean / gradient 1e-2.  When the
-a-posteriori guard rejects the fp32 Gram matrix the bound is the fp64 one (1e-10) and only
-the gradient contraction is fp32.
+object is fp64.  Default: only the gradient contraction is fp32 -- the bound is the fp64 one
+(1e-10), hyper-parameter gradients 5e-3, dZ 5e-2 (max-norm relative).  With "f32_phi" = 1 and the
+fp32 Gram matrix accepted by the guard (mode 3): bound 1e-4 rel, hyper-parameter gradients 2e-3,
+dZ 3e-2, posterior mean / gradient 1e-2.
 """
 import numpy as np
 import pytest
@@ -68,6 +68,7 @@ def test_fp32_gram_accepted(hip, kind):
     X, y, Z = _problem(N, M, D, 11)
     ls = np.full(D, 0.9 * np.sqrt(D))
     hip.set_option("precision", 32)
+    hip.set_option("f32_phi", 1)
     try:
         hip.set_data(X, y); hip.set_inducing(Z)
         hip.set_kernel([kind], [1.3], ls[None, :], 0.05)
@@ -77,6 +78,7 @@ def test_fp32_gram_accepted(hip, kind):
         mean, _ = hip.predict(X[:64], want_var=False)
         jac = hip.predict_grad(X[:64])
     finally:
+        hip.set_option("f32_phi", 0)
         hip.set_option("precision", 64)
     assert int(mode[0]) == 3 and 0.0 < mode[1] <= 1.0
     g, mu, J = _oracle(kind, X, y, Z, 1.3, ls, 0.05)
@@ -99,6 +101,7 @@ def test_fp32_gram_rejected_falls_back_to_fp64_bound(hip):
     hip.set_kernel(["RBF"], [1.3], ls[None, :], 0.05)
     ref = hip.sparse_lml_grad()
     hip.set_option("precision", 32)
+    hip.set_option("f32_phi", 1)
     try:
         hip.set_data(X, y); hip.set_inducing(Z)
         hip.set_kernel(["RBF"], [1.3], ls[None, :], 0.05)
@@ -107,6 +110,7 @@ def test_fp32_gram_rejected_falls_back_to_fp64_bound(hip):
         second = hip.sparse_lml()
         mode2 = int(hip.get("MODE", (2,))[0])
     finally:
+        hip.set_option("f32_phi", 0)
         hip.set_option("precision", 64)
     assert mode1 in (1, 2) and mode2 in (1, 2)
     assert abs(first[0] - ref[0]) <= 1e-10 * abs(ref[0])          # the bound is the fp64 one
@@ -123,6 +127,7 @@ def test_fp32_chunked_rows_match_resident(hip):
     ls = np.full(D, np.sqrt(D))
     out = []
     hip.set_option("precision", 32)
+    hip.set_option("f32_phi", 1)
     try:
         for chunk in (131072, 1024):
             hip.set_option("chunk_rows", chunk)
@@ -131,6 +136,7 @@ def test_fp32_chunked_rows_match_resident(hip):
             out.append(hip.sparse_lml_grad())
     finally:
         hip.set_option("chunk_rows", 131072)
+        hip.set_option("f32_phi", 0)
         hip.set_option("precision", 64)
     a, b = out
     # different chunking = different fp32 accumulation chains of Phi: both are within the 1e-4 class of
