@@ -243,6 +243,11 @@ struct Globals { double N, yy; };
 static int get_globals(Ctx* c, Globals* g) {
     g->N = (double)c->N;
     g->yy = c->yy_local;
+    if (c->comm && c->glob_valid) {        // all-reduced once per data set (every rank takes this branch together)
+        g->N = c->glob_N;
+        g->yy = c->glob_yy;
+        return EDRGP_OK;
+    }
     if (c->comm) {
         TRY(c->red.reserve(2 * sizeof(double)));
         double h[2] = {g->N, g->yy};
@@ -252,6 +257,9 @@ static int get_globals(Ctx* c, Globals* g) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         g->N = h[0];
         g->yy = h[1];
+        c->glob_N = h[0];
+        c->glob_yy = h[1];
+        c->glob_valid = true;
     }
     return EDRGP_OK;
 }
@@ -1040,6 +1048,7 @@ int edrgp_set_data(edrgp_ctx* ctx, const double* X, const double* y, int64_t N, 
     c->D = D;
     c->xq32_valid = false;
     c->phi32_bad = false;
+    c->glob_valid = false;
     TRY(build_xtilde(c, c->X.d(), N, D, c->Xt.d()));
     TRY(build_xq(c, c->X.d(), N, D, c->Xq.d()));
     TRY(sum_sq(c, c->y.d(), N, c->scal.d() + SC_YY));
@@ -1071,6 +1080,7 @@ int edrgp_set_data_projected(edrgp_ctx* ctx, const double* Xbase, const double* 
         HIP_TRY(hipMemcpyAsync(&yy, c->scal.d() + SC_YY, sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->yy_local = yy;
+        c->glob_valid = false;
         c->base_N = N;
         c->base_D = Dbase;
     } else if (c->base_N != N || c->base_D != Dbase) {

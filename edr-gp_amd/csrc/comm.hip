@@ -48,6 +48,7 @@ int edrgp_comm_init(edrgp_ctx* ctx, int nranks, int rank, const void* id128) {
     ncclComm_t comm;
     NCCL_TRY(ncclCommInitRank(&comm, nranks, id, rank));
     c->comm = comm;
+    c->glob_valid = false;
     c->nranks = nranks;
     c->rank = rank;
     return EDRGP_OK;
@@ -60,6 +61,7 @@ int edrgp_comm_destroy(edrgp_ctx* ctx) {
     (void)hipStreamSynchronize(c->stream);
     ncclResult_t r = ncclCommDestroy(static_cast<ncclComm_t>(c->comm));
     c->comm = nullptr;
+    c->glob_valid = false;
     c->nranks = 1;
     c->rank = 0;
     if (r != ncclSuccess) { set_error("ncclCommDestroy: %s", ncclGetErrorString(r)); return EDRGP_ERR_COMM; }

@@ -237,6 +237,8 @@ struct Ctx {
     DBuf X, y, Z, Xt, Zt, Xq;         // Xt = [X|1|X.^2], Zt likewise for Z, Xq = [X|X.^2]
     bool have_data = false, have_Z = false, have_kernel = false;
     double yy_local = 0.0;
+    bool glob_valid = false;          // [N, y'y] summed over the ranks, once per data set
+    double glob_N = 0.0, glob_yy = 0.0;
 
     // kernel (host copy)
     int nparts = 0;
