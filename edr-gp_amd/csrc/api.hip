@@ -1010,6 +1010,7 @@ int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
     else if (!std::strcmp(key, "rbf_epilogue")) c->rbf_epilogue = (value != 0.0);
     else if (!std::strcmp(key, "chol_fused")) c->chol_fused = (value != 0.0);
     else if (!std::strcmp(key, "syrk_xmap")) c->syrk_xmap = (value != 0.0);
+    else if (!std::strcmp(key, "syrk_diag_opt")) c->syrk_diag_opt = (value != 0.0);
     else if (!std::strcmp(key, "mask_layout")) c->mask_layout = (int)value;
     else if (!std::strcmp(key, "side_cus")) {
         // CUs reserved for the side stream of bound-only evaluations (0 = plain streams); takes effect

@@ -219,6 +219,7 @@ struct Ctx {
     int overlap = 3;                  // 0 none; 1 Kmm gradient term beside the gradient contraction;
                                       // 2 also phase 1 beside the row pass (stretches the Phi kernel);
                                       // 3 = 2 for bound-only evaluations, 1 for gradient evaluations
+    bool syrk_diag_opt = true;        // Phi: diagonal tiles compute their 36 lower 16x16 blocks only
     bool syrk_xmap = true;            // Phi: split-major workgroup -> XCD map (la_gemm.hip)
     bool chol_fused = true;           // Cholesky: panel + trailing update in one launch per step (la_chol.hip)
     bool rbf_epilogue = true;         // RBF: fused gradient epilogue takes h(r) = -k(r) from the resident K_nm

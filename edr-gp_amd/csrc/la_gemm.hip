@@ -46,6 +46,7 @@ struct GemmArgs {
     int fuse_on;
     int dephase;        // 0 none; 1 s_setprio on odd wave slots; 2 half-tile start delay on odd wave slots
     int xmap;           // 1: split-major XCD map (see the kernel)
+    int diag_opt;       // 1: diagonal tiles of the Phi contraction compute their lower blocks only
     int kmode;          // triangular operands: bit0 k <= row tile end, bit1 k >= row tile start,
                         //                      bit2 k <= col tile end, bit3 k >= col tile start
 };
@@ -142,6 +143,193 @@ struct TileLoader {
     }
 };
 
+// Diagonal tiles of the Phi contraction (128x128; the A and B panels are the same 128 columns of K_nm):
+// only the 36 lower 16x16 blocks are needed.  Wave w takes block-rows w and 7-w (w+1 and 8-w blocks = 9
+// each: perfectly balanced), so a diagonal tile issues 9 MFMAs per wave and k-step instead of 16, stages ONE
+// panel instead of two, and never computes the upper halves (the slab reduction reads the lower triangle
+// only).  Same pipeline as the main loop: register prefetch of tile t+1, mid-phase LDS staging, one barrier
+// per k-tile, staging at raised priority.
+template <int W, typename LAT>
+__device__ __forceinline__ void diag_tile_run(const GemmArgs& g, const double* __restrict__ A, double* __restrict__ C,
+                                              double (*As)[LAT::SIZE], int tid, int lr, int lq, int m0, int kt0, int kt1) {
+    // k-major panel, staged exactly like TileLoader<128, true> (kept as plain locals: the struct form ended up in
+    // scratch memory here)
+    static_assert(LAT::NV == 4, "diag_tile_run is written for the 128-wide k-major panel");
+    const int kr = tid >> 6, mc = (tid & 63) * 2;                 // thread -> k-row kr + 4 v, columns mc, mc + 1
+    const unsigned o0 = (unsigned)(((kr) * g.lda + mc) * 8), o1 = (unsigned)(((kr + 4) * g.lda + mc) * 8);
+    const unsigned o2 = (unsigned)(((kr + 8) * g.lda + mc) * 8), o3 = (unsigned)(((kr + 12) * g.lda + mc) * 8);
+    const int l0 = LAT::idx(kr, mc), l1 = LAT::idx(kr + 4, mc), l2 = LAT::idx(kr + 8, mc), l3 = LAT::idx(kr + 12, mc);
+    const char* base = reinterpret_cast<const char*>(A + LAT::tile_origin(g.lda, m0, kt0));
+    const long long step = LAT::tile_step(g.lda);
+    double2 r0 = {0.0, 0.0}, r1 = r0, r2 = r0, r3 = r0;
+    if (kt0 < kt1) {                     // an empty row range (more splits than k-tiles) stores zeros
+        r0 = *reinterpret_cast<const double2*>(base + o0);
+        r1 = *reinterpret_cast<const double2*>(base + o1);
+        r2 = *reinterpret_cast<const double2*>(base + o2);
+        r3 = *reinterpret_cast<const double2*>(base + o3);
+    }
+    *reinterpret_cast<double2*>(&As[0][l0]) = r0;
+    *reinterpret_cast<double2*>(&As[0][l1]) = r1;
+    *reinterpret_cast<double2*>(&As[0][l2]) = r2;
+    *reinterpret_cast<double2*>(&As[0][l3]) = r3;
+    __syncthreads();
+    d4 acc[9];
+#pragma unroll
+    for (int f = 0; f < 9; ++f) acc[f] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        const bool more = (kt + 1 < kt1);
+        if (more) {
+            base += step;
+            r0 = *reinterpret_cast<const double2*>(base + o0);
+            r1 = *reinterpret_cast<const double2*>(base + o1);
+            r2 = *reinterpret_cast<const double2*>(base + o2);
+            r3 = *reinterpret_cast<const double2*>(base + o3);
+        }
+        if (g.dephase == 3) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            const int krow = kk * 4 + lq;
+            const double a0 = As[buf][LAT::idx(krow, W * 16 + lr)];
+            const double a1 = As[buf][LAT::idx(krow, (7 - W) * 16 + lr)];
+            double b[8 - W];
+#pragma unroll
+            for (int j = 0; j < 8 - W; ++j) b[j] = As[buf][LAT::idx(krow, j * 16 + lr)];
+#pragma unroll
+            for (int j = 0; j <= W; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b[j], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 8 - W; ++j)
+                acc[W + 1 + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b[j], acc[W + 1 + j], 0, 0, 0);
+            if (kk == BK / 4 - 2) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+                    *reinterpret_cast<double2*>(&As[buf ^ 1][l0]) = r0;
+                    *reinterpret_cast<double2*>(&As[buf ^ 1][l1]) = r1;
+                    *reinterpret_cast<double2*>(&As[buf ^ 1][l2]) = r2;
+                    *reinterpret_cast<double2*>(&As[buf ^ 1][l3]) = r3;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (g.dephase == 3) __builtin_amdgcn_s_setprio(2);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j <= W; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) C[(size_t)(m0 + W * 16 + lq + 4 * r) * g.ldc + m0 + j * 16 + lr] = acc[j][r];
+#pragma unroll
+    for (int j = 0; j < 8 - W; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            C[(size_t)(m0 + (7 - W) * 16 + lq + 4 * r) * g.ldc + m0 + j * 16 + lr] = acc[W + 1 + j][r];
+}
+
+// Two diagonal tiles (column blocks d0 and d1) in one workgroup: 18 MFMAs per wave and k-step keep the MFMA
+// phase of a k-tile as long as a regular tile's 16, so the one-tile-ahead prefetch still covers the load latency
+// (a lone diagonal tile with 9 was load-latency-bound and gained nothing).  Panel d0 is staged in As, d1 in Bs.
+template <int W, typename LAT>
+__device__ __forceinline__ void diag_pair_run(const GemmArgs& g, const double* __restrict__ A, double* __restrict__ C,
+                                              double (*As)[LAT::SIZE], double (*Bs)[LAT::SIZE], int tid, int lr, int lq,
+                                              int c0, int c1, int kt0, int kt1) {
+    static_assert(LAT::NV == 4, "diag_pair_run is written for the 128-wide k-major panel");
+    const int kr = tid >> 6, mc = (tid & 63) * 2;
+    const unsigned o0 = (unsigned)(((kr) * g.lda + mc) * 8), o1 = (unsigned)(((kr + 4) * g.lda + mc) * 8);
+    const unsigned o2 = (unsigned)(((kr + 8) * g.lda + mc) * 8), o3 = (unsigned)(((kr + 12) * g.lda + mc) * 8);
+    const int l0 = LAT::idx(kr, mc), l1 = LAT::idx(kr + 4, mc), l2 = LAT::idx(kr + 8, mc), l3 = LAT::idx(kr + 12, mc);
+    const char* ba = reinterpret_cast<const char*>(A + LAT::tile_origin(g.lda, c0, kt0));
+    const char* bb = reinterpret_cast<const char*>(A + LAT::tile_origin(g.lda, c1, kt0));
+    const long long step = LAT::tile_step(g.lda);
+    double2 r0 = {0.0, 0.0}, r1 = r0, r2 = r0, r3 = r0, q0 = r0, q1 = r0, q2 = r0, q3 = r0;
+    if (kt0 < kt1) {                     // an empty row range (more splits than k-tiles) stores zeros
+        r0 = *reinterpret_cast<const double2*>(ba + o0);
+        r1 = *reinterpret_cast<const double2*>(ba + o1);
+        r2 = *reinterpret_cast<const double2*>(ba + o2);
+        r3 = *reinterpret_cast<const double2*>(ba + o3);
+        q0 = *reinterpret_cast<const double2*>(bb + o0);
+        q1 = *reinterpret_cast<const double2*>(bb + o1);
+        q2 = *reinterpret_cast<const double2*>(bb + o2);
+        q3 = *reinterpret_cast<const double2*>(bb + o3);
+    }
+    *reinterpret_cast<double2*>(&As[0][l0]) = r0;
+    *reinterpret_cast<double2*>(&As[0][l1]) = r1;
+    *reinterpret_cast<double2*>(&As[0][l2]) = r2;
+    *reinterpret_cast<double2*>(&As[0][l3]) = r3;
+    *reinterpret_cast<double2*>(&Bs[0][l0]) = q0;
+    *reinterpret_cast<double2*>(&Bs[0][l1]) = q1;
+    *reinterpret_cast<double2*>(&Bs[0][l2]) = q2;
+    *reinterpret_cast<double2*>(&Bs[0][l3]) = q3;
+    __syncthreads();
+    d4 acc[18];
+#pragma unroll
+    for (int f = 0; f < 18; ++f) acc[f] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        const bool more = (kt + 1 < kt1);
+        if (more) {
+            ba += step;
+            bb += step;
+            r0 = *reinterpret_cast<const double2*>(ba + o0);
+            r1 = *reinterpret_cast<const double2*>(ba + o1);
+            r2 = *reinterpret_cast<const double2*>(ba + o2);
+            r3 = *reinterpret_cast<const double2*>(ba + o3);
+            q0 = *reinterpret_cast<const double2*>(bb + o0);
+            q1 = *reinterpret_cast<const double2*>(bb + o1);
+            q2 = *reinterpret_cast<const double2*>(bb + o2);
+            q3 = *reinterpret_cast<const double2*>(bb + o3);
+        }
+        if (g.dephase == 3) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            const int krow = kk * 4 + lq;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const double* S = h ? Bs[buf] : As[buf];
+                const double a0 = S[LAT::idx(krow, W * 16 + lr)];
+                const double a1 = S[LAT::idx(krow, (7 - W) * 16 + lr)];
+                double b[8 - W];
+#pragma unroll
+                for (int j = 0; j < 8 - W; ++j) b[j] = S[LAT::idx(krow, j * 16 + lr)];
+#pragma unroll
+                for (int j = 0; j <= W; ++j)
+                    acc[9 * h + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b[j], acc[9 * h + j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 8 - W; ++j)
+                    acc[9 * h + W + 1 + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b[j], acc[9 * h + W + 1 + j], 0, 0, 0);
+            }
+            if (kk == BK / 4 - 2) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+                    *reinterpret_cast<double2*>(&As[buf ^ 1][l0]) = r0;
+                    *reinterpret_cast<double2*>(&As[buf ^ 1][l1]) = r1;
+                    *reinterpret_cast<double2*>(&As[buf ^ 1][l2]) = r2;
+                    *reinterpret_cast<double2*>(&As[buf ^ 1][l3]) = r3;
+                    *reinterpret_cast<double2*>(&Bs[buf ^ 1][l0]) = q0;
+                    *reinterpret_cast<double2*>(&Bs[buf ^ 1][l1]) = q1;
+                    *reinterpret_cast<double2*>(&Bs[buf ^ 1][l2]) = q2;
+                    *reinterpret_cast<double2*>(&Bs[buf ^ 1][l3]) = q3;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (g.dephase == 3) __builtin_amdgcn_s_setprio(2);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int c = h ? c1 : c0;
+#pragma unroll
+        for (int j = 0; j <= W; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(size_t)(c + W * 16 + lq + 4 * r) * g.ldc + c + j * 16 + lr] = acc[9 * h + j][r];
+#pragma unroll
+        for (int j = 0; j < 8 - W; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                C[(size_t)(c + (7 - W) * 16 + lq + 4 * r) * g.ldc + c + j * 16 + lr] = acc[9 * h + W + 1 + j][r];
+    }
+}
+
 // TAG only changes the kernel symbol, so the Phi syrk (1) and the gradient
 // contraction W = K S (2) show up under their own names in rocprofv3 traces.
 template <int BM, int BN, bool AKM, bool BKM, int TAG>
@@ -192,7 +380,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + in;
     }
     int ti, tj;
-    if (g.tri) {
+    int pair_d0 = -1;                  // Phi with diag_opt: >= 0 -> this workgroup owns diagonal tiles d0 (and d0 + 1)
+    if (g.tri && g.diag_opt) {
+        // strictly lower tiles first, then the diagonal tiles two per workgroup (measured: leading with the
+        // pair workgroups instead is 2-3 % slower)
+        const int n_strict = g.tiles_m * (g.tiles_m - 1) / 2;
+        if (t < n_strict) {
+            ti = (int)((sqrt(8.0 * (double)t + 1.0) + 1.0) * 0.5);
+            while ((long long)ti * (ti + 1) / 2 <= t) ++ti;
+            while ((long long)ti * (ti - 1) / 2 > t) --ti;
+            tj = t - (int)((long long)ti * (ti - 1) / 2);
+        } else {
+            pair_d0 = 2 * (t - n_strict);
+            ti = tj = pair_d0;
+        }
+    } else if (g.tri) {
         ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
         while ((long long)(ti + 1) * (ti + 2) / 2 <= t) ++ti;
         while ((long long)ti * (ti + 1) / 2 > t) --ti;
@@ -226,6 +428,27 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         if (g.kmode & 8) k_lo = max(k_lo, n0);
         kt0 = max(kt0, k_lo / BK);
         kt1 = min(kt1, (k_hi + BK - 1) / BK);
+    }
+
+    if constexpr (TAG == 1 && BM == 128 && BN == 128 && AKM && BKM) {
+        // Phi: the diagonal tiles run the 36-block loops, two tiles per workgroup
+        // (the host enables diag_opt only for full tiles, full k-tiles and 16-byte aligned rows)
+        if (pair_d0 >= 0) {
+            const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+            if (pair_d0 + 1 < g.tiles_m) {
+                const int c0 = pair_d0 * BM, c1 = c0 + BM;
+                if (wave_u == 0) diag_pair_run<0, LA>(g, A, C, As, Bs, tid, lr, lq, c0, c1, kt0, kt1);
+                else if (wave_u == 1) diag_pair_run<1, LA>(g, A, C, As, Bs, tid, lr, lq, c0, c1, kt0, kt1);
+                else if (wave_u == 2) diag_pair_run<2, LA>(g, A, C, As, Bs, tid, lr, lq, c0, c1, kt0, kt1);
+                else diag_pair_run<3, LA>(g, A, C, As, Bs, tid, lr, lq, c0, c1, kt0, kt1);
+            } else {                                       // odd tile count: the last diagonal tile alone
+                if (wave_u == 0) diag_tile_run<0, LA>(g, A, C, As, tid, lr, lq, m0, kt0, kt1);
+                else if (wave_u == 1) diag_tile_run<1, LA>(g, A, C, As, tid, lr, lq, m0, kt0, kt1);
+                else if (wave_u == 2) diag_tile_run<2, LA>(g, A, C, As, tid, lr, lq, m0, kt0, kt1);
+                else diag_tile_run<3, LA>(g, A, C, As, tid, lr, lq, m0, kt0, kt1);
+            }
+            return;
+        }
     }
 
     d4 acc[TM][TN];
@@ -292,6 +515,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
             if (g.dephase == 4) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) {
+                {
                 double a[TM], b[TN];
 #pragma unroll
                 for (int x = 0; x < TM; ++x) a[x] = As[buf][LA::idx(kk * 4 + lq, wm * WM + x * 16 + lr)];
@@ -302,6 +526,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 #pragma unroll
                     for (int y = 0; y < TN; ++y)
                         acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);
+                }
                 if (EARLY_STORE && kk == BK / 4 - 2) {
                     // The next tile's registers go to the free LDS buffer in the MIDDLE of the
                     // MFMA phase (their loads were issued two k-steps ago), so the write latency
@@ -654,6 +879,7 @@ static int gemm_impl(Ctx* c, bool transA, bool transB, int M, int N, int K, doub
     g.tri = o.tri;
     g.kmode = o.kmode;
     g.xmap = (o.tag == 1 || o.tag == 9) && o.tri && splits > 1 && o.batch == 1 && c->syrk_xmap;
+    g.diag_opt = 0;
     g.dephase = c->gemm_dephase;
     g.stamps = nullptr;
     g.fuse_on = 0;
@@ -685,7 +911,12 @@ static int gemm_impl(Ctx* c, bool transA, bool transB, int M, int N, int K, doub
     } else {
         g.C = C; g.ldc = ldc; g.alpha = alpha; g.beta = beta; g.slabStride = 0;
     }
-    const long long nt = o.tri ? (long long)g.tiles_m * (g.tiles_m + 1) / 2 : (long long)g.tiles_m * g.tiles_n;
+    // Phi only: diagonal tiles as 36-block loops, two per workgroup (full tiles, full k-tiles, aligned rows)
+    g.diag_opt = (o.tag == 1) && o.tri && slab != nullptr && c->syrk_diag_opt && tile == 128 && transA && !transB &&
+                 (M % 128 == 0) && (K % BK == 0) && g.vecA && ((long long)BK * lda < (1LL << 28)) && A == B && lda == ldb &&
+                 o.batch == 1;
+    long long nt = o.tri ? (long long)g.tiles_m * (g.tiles_m + 1) / 2 : (long long)g.tiles_m * g.tiles_n;
+    if (g.diag_opt) nt = (long long)g.tiles_m * (g.tiles_m - 1) / 2 + (g.tiles_m + 1) / 2;
     dim3 grid((unsigned)nt, (unsigned)splits, (unsigned)o.batch);
     // op(A) is M x K: not transposed -> stored [M][K] (m-major); transposed -> stored [K][M] (k-major)
     const bool akm = transA;
@@ -762,7 +993,9 @@ int pick_syrk_splits(Ctx* c, long long nt, int kt, int64_t rows, int M, int tile
     double best_cost = 1e300;
     for (int s = 1; s <= max_splits; ++s) {
         const long long rounds = (nt * s + slots - 1) / slots;
-        const double cost = (double)rounds * t_full / s + s * t_slab;
+        // + 1/8 round: workgroups are not equally long (a diagonal-pair workgroup issues 18 MFMAs per k-step
+        // against 16), so the last round overhangs; more, shorter rounds absorb that better
+        const double cost = ((double)rounds + 0.125) * t_full / s + s * t_slab;
         if (cost < best_cost * (1.0 - 1e-3)) { best_cost = cost; best = s; }
     }
     return best;
@@ -772,12 +1005,18 @@ int syrk_tn(Ctx* c, const double* K, int64_t rows, int M, int ldk, double* Phi, 
     if (rows > 0x7fffffffLL) { set_error("syrk_tn: rows chunk too large"); return EDRGP_ERR_INVALID; }
     const int tile = (M >= 256) ? 128 : 64;
     const int tm = (M + tile - 1) / tile;
-    const long long nt = (long long)tm * (tm + 1) / 2;
+    long long nt = (long long)tm * (tm + 1) / 2;
+    if (c->syrk_diag_opt && tile == 128 && M % 128 == 0 && rows % BK == 0 && ldk % 2 == 0)
+        nt = (long long)tm * (tm - 1) / 2 + (tm + 1) / 2;          // diagonal tiles go two per workgroup (gemm_impl)
     const int kt = (int)((rows + BK - 1) / BK);
     int splits = c->syrk_splits;
     if (splits <= 0) splits = pick_syrk_splits(c, nt, kt, rows, M, tile, 8);
     if (splits < 1) splits = 1;
     if (splits > kt) splits = std::max(1, kt);
+    {
+        const int per = (kt + splits - 1) / splits;           // no empty trailing row ranges
+        splits = (kt + per - 1) / per;
+    }
     const long long slabStride = (long long)M * M;
     TRY(c->slabs.reserve((size_t)splits * slabStride * sizeof(double)));
     GemmOpts o;
