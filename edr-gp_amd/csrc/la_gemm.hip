@@ -330,6 +330,38 @@ __device__ __forceinline__ void diag_pair_run(const GemmArgs& g, const double* _
     }
 }
 
+// Workgroup reduction at the end of the fused gradient epilogue: column sums of T (8 partials per column:
+// 2 row-waves x 4 lane rows) and the d/dvariance partial, with TWO barriers -- a barrier beside the partner
+// workgroup's MFMA stream costs ~2 us, and the first version spent eleven of them (0.5 ms per launch at Cm).
+// Everything goes through LDS once; wave 2 folds the 256 d/dvariance partials (4 per lane, then a fixed
+// shuffle tree), waves 0-1 the columns.
+template <int BN, int WN, int TN>
+__device__ __forceinline__ void fused_epilogue_reduce(const FuseT& f, const double (&csum)[TN], double dv,
+                                                       double* __restrict__ lds, int tid, int wm, int wn, int lr, int lq,
+                                                       int n0, int N, int ti, size_t dv_slot) {
+    __syncthreads();                               // the operand tiles in LDS are dead from here
+    double* redc = lds;                            // [8][BN] column partials
+    double* redv = lds + 8 * BN;                   // [256] d/dvariance partials
+#pragma unroll
+    for (int y = 0; y < TN; ++y) redc[((wm * 4 + lq) * BN) + wn * WN + y * 16 + lr] = csum[y];
+    redv[tid] = dv;
+    __syncthreads();
+    if (tid < BN) {
+        if (f.cspart != nullptr) {
+            double sum = 0.0;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) sum += redc[p * BN + tid];
+            if (n0 + tid < N) f.cspart[(size_t)ti * N + n0 + tid] = sum;
+        }
+    } else if (tid < BN + 64) {
+        const int l = tid - BN;
+        double v = (redv[l] + redv[l + 64]) + (redv[l + 128] + redv[l + 192]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (l == 0) f.dvpart[dv_slot] = v / f.var;
+    }
+}
+
 // TAG only changes the kernel symbol, so the Phi syrk (1) and the gradient
 // contraction W = K S (2) show up under their own names in rocprofv3 traces.
 template <int BM, int BN, bool AKM, bool BKM, int TAG>
@@ -684,28 +716,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                         }
                     }
                 }
-            if (f.cspart != nullptr) {
-                __syncthreads();
-                double* redc = &Bs[0][0];
-#pragma unroll
-                for (int y = 0; y < TN; ++y) redc[((wm * 4 + lq) * BN) + wn * WN + y * 16 + lr] = csum[y];
-                __syncthreads();
-                for (int j = tid; j < BN; j += 256) {
-                    double sum = 0.0;
-#pragma unroll
-                    for (int p = 0; p < 8; ++p) sum += redc[p * BN + j];
-                    if (n0 + j < g.N) f.cspart[(size_t)ti * g.N + n0 + j] = sum;
-                }
-            }
-            __syncthreads();
-            double* red = &As[0][0];
-            red[tid] = dv;
-            __syncthreads();
-            for (int o = 128; o > 0; o >>= 1) {
-                if (tid < o) red[tid] += red[tid + o];
-                __syncthreads();
-            }
-            if (tid == 0) f.dvpart[(size_t)blockIdx.z * gridDim.x + blockIdx.x] = red[0] / f.var;
+            fused_epilogue_reduce<BN, WN, TN>(f, csum, dv, &Bs[0][0], tid, wm, wn, lr, lq, n0, g.N, ti,
+                                              (size_t)blockIdx.z * gridDim.x + blockIdx.x);
             return;
         }
         // one feature chunk (the host fuses only when D <= DC): stage, then one row block
@@ -774,31 +786,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                 }
             }
         }
-        if (f.cspart != nullptr) {
-            // column sums of T over the tile's rows (the "ones" column of T^T [X | 1 | X.^2]):
-            // 8 partials per column (2 row-waves x 4 lane rows), fixed order
-            __syncthreads();
-            double* redc = &Bs[0][0];
-#pragma unroll
-            for (int y = 0; y < TN; ++y) redc[((wm * 4 + lq) * BN) + wn * WN + y * 16 + lr] = csum[y];
-            __syncthreads();
-            for (int j = tid; j < BN; j += 256) {
-                double sum = 0.0;
-#pragma unroll
-                for (int p = 0; p < 8; ++p) sum += redc[p * BN + j];
-                if (n0 + j < g.N) f.cspart[(size_t)ti * g.N + n0 + j] = sum;
-            }
-        }
-        // fixed-order workgroup reduction of the d/dvariance partial
-        __syncthreads();
-        double* red = &As[0][0];
-        red[tid] = dv;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if (tid < o) red[tid] += red[tid + o];
-            __syncthreads();
-        }
-        if (tid == 0) f.dvpart[(size_t)blockIdx.z * gridDim.x + blockIdx.x] = red[0] / f.var;
+        fused_epilogue_reduce<BN, WN, TN>(f, csum, dv, &Bs[0][0], tid, wm, wn, lr, lq, n0, g.N, ti,
+                                          (size_t)blockIdx.z * gridDim.x + blockIdx.x);
         return;
     }
 
