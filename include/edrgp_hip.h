@@ -89,7 +89,11 @@ int  edrgp_sync(edrgp_ctx* ctx);
  * for single-part kernels with D <= 64 while Kmm is conditioned for the Gram form; the bound itself stays
  * fp64.  "f32_phi" = 1 additionally tries the Gram matrix Phi in fp32 and keeps it only if the
  * factorisation of I + A succeeds without jitter and an error estimate stays below "f32_guard"
- * (EDRGP_GET_MODE reports 3 then; the bound is 1e-4..1e-3 accurate in that mode)) */
+ * (EDRGP_GET_MODE reports 3 then; the bound is 1e-4..1e-3 accurate in that mode)).
+ * A/B switches of individual optimisations, all on by default and result-neutral: "fuse_grad",
+ * "rbf_epilogue", "syrk_xmap", "syrk_diag_opt", "chol_fused", "mfma_kbuild", "kbuild_tile" (64 / 128),
+ * "gemm_dephase", "tri_tile"; "side_cus" (CU-masked stream pair for bound-only evaluations, default 0 = off);
+ * "trace" (host-side phase timing to stderr). */
 int  edrgp_set_option(edrgp_ctx* ctx, const char* key, double value);
 
 /* Training data (already validated / normalised by the host: check_X_y at
