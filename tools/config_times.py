@@ -9,7 +9,8 @@ from edrgp_amd.sweep import projection_sweep
 h = HipGP(0)
 
 def timeit(f, n=5):
-    f(); f()
+    for _ in range(6):          # warm-up incl. the one-time ~70 ms queue / allocation cost of a fresh process
+        f()
     t0 = time.perf_counter()
     for _ in range(n):
         f()
