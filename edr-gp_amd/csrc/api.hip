@@ -303,6 +303,7 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
     const int64_t N = c->N;
     const int Wd = 2 * D + 1;
     const int np = c->nparts;
+    c->knm_train_valid = false;
     const double beta = 1.0 / std::max(c->noise_var, 1e-8);
     const KSpec ks = make_kspec(c);
     Globals gl;
@@ -407,6 +408,7 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
             TRY(syrk_tn(c, S, rows, M, M, Phi, M, ch > 0));
         }
         k_resident = (nchunks == 1);
+        c->knm_train_valid = k_resident;          // (the stable form keeps K_nm in Knm and K_nm Li^T in W)
         if (c->comm) TRY(allreduce_sum(c, Phi, (size_t)M * M + M));
         return EDRGP_OK;
     };
@@ -869,6 +871,9 @@ static int predict_rows(Ctx* c, const double* Xs_dev, int64_t Ns, double* mean_h
     double* o_mean = o_jac + (size_t)chunk * D;
     double* o_var = o_mean + chunk;
     const double kdiag = var_sum(c);
+    // the training rows right after a sparse evaluation with the same theta / Z: K(X, Z) is still resident
+    const bool k_train = c->knm_train_valid && !c->post_dense && Xs_dev == c->X.d() && Ns == c->N && Mp == c->M;
+    if (!k_train) c->knm_train_valid = false;          // Knm is about to be overwritten chunk by chunk
     const bool want_gram = (gram_h != nullptr);
     double* d_gram = nullptr;
     double* d_ones = nullptr;
@@ -881,8 +886,8 @@ static int predict_rows(Ctx* c, const double* Xs_dev, int64_t Ns, double* mean_h
     for (int64_t r0 = 0; r0 < Ns; r0 += chunk) {
         const int64_t rows = std::min<int64_t>(chunk, Ns - r0);
         TRY(predict_chunk(c, ks, Xs_dev + (size_t)r0 * D, rows, Pp, Pt, Mp, c->wv.d(), c->winv.d(), kdiag,
-                          c->Knm.d(), c->W.d(), GT, mean_h ? o_mean : nullptr, var_h ? o_var : nullptr,
-                          (jac_h || want_gram) ? o_jac : nullptr));
+                          k_train ? c->Knm.d() + (size_t)r0 * Mp : c->Knm.d(), c->W.d(), GT, mean_h ? o_mean : nullptr,
+                          var_h ? o_var : nullptr, (jac_h || want_gram) ? o_jac : nullptr, k_train));
         if (want_gram) {
             TRY(gemm(c, true, false, D, D, (int)rows, 1.0, o_jac, D, o_jac, D, r0 > 0 ? 1.0 : 0.0, d_gram, D));
             TRY(gemm(c, true, false, D, 1, (int)rows, 1.0, o_jac, D, d_ones, 1, r0 > 0 ? 1.0 : 0.0, d_gram + (size_t)D * D, 1));
@@ -959,7 +964,7 @@ int edrgp_ctx_destroy(edrgp_ctx* ctx) {
     (void)hipStreamSynchronize(c->stream2);
     c->drain_events();
     if (c->comm) edrgp_comm_destroy(ctx);
-    DBuf* bufs[] = {&c->Xbase, &c->X, &c->y, &c->Z, &c->Xt, &c->Zt, &c->Xq, &c->g2, &c->Knm32, &c->T32, &c->S2f, &c->Xq32,
+    DBuf* bufs[] = {&c->ptw, &c->Xbase, &c->X, &c->y, &c->Z, &c->Xt, &c->Zt, &c->Xq, &c->g2, &c->Knm32, &c->T32, &c->S2f, &c->Xq32,
                     &c->ks32_x, &c->ks32_z, &c->ks32_xn, &c->ks32_zn, &c->invl, &c->wv, &c->winv, &c->Knm, &c->W, &c->T, &c->slabs,
                     &c->bpart, &c->scal, &c->info, &c->gt_nm, &c->gt_mm, &c->panel, &c->trtri_ws, &c->dinv, &c->red};
     for (DBuf* b : bufs) b->release();
@@ -1050,6 +1055,7 @@ int edrgp_set_data(edrgp_ctx* ctx, const double* X, const double* y, int64_t N, 
     c->xq32_valid = false;
     c->phi32_bad = false;
     c->glob_valid = false;
+    c->knm_train_valid = false;
     TRY(build_xtilde(c, c->X.d(), N, D, c->Xt.d()));
     TRY(build_xq(c, c->X.d(), N, D, c->Xq.d()));
     TRY(sum_sq(c, c->y.d(), N, c->scal.d() + SC_YY));
@@ -1100,6 +1106,7 @@ int edrgp_set_data_projected(edrgp_ctx* ctx, const double* Xbase, const double* 
     TRY(gemm(c, false, false, (int)N, d, Dbase, 1.0, c->Xbase.d(), Dbase, c->tmpvec[5].d(), d, 0.0, c->X.d(), d));
     c->N = N;
     c->D = d;
+    c->knm_train_valid = false;
     c->xq32_valid = false;
     c->phi32_bad = false;
     TRY(build_xtilde(c, c->X.d(), N, d, c->Xt.d()));
@@ -1120,6 +1127,7 @@ int edrgp_set_inducing(edrgp_ctx* ctx, const double* Z, int M) {
     TRY(build_xtilde(c, c->Z.d(), M, D, c->Zt.d()));
     HIP_TRY(hipStreamSynchronize(c->stream));   // Z is a borrowed host pointer
     if (c->M != M) c->phi32_bad = false;
+    c->knm_train_valid = false;
     c->M = M;
     c->have_Z = true;
     if (!c->post_dense) c->have_post = false;
@@ -1157,6 +1165,7 @@ int edrgp_set_kernel(edrgp_ctx* ctx, int nparts, const int* kinds, const double*
     HIP_TRY(hipMemcpy(c->invl.d(), invl.data(), invl.size() * sizeof(double), hipMemcpyHostToDevice));
     c->have_kernel = true;
     c->have_post = false;
+    c->knm_train_valid = false;
     return EDRGP_OK;
 }
 
@@ -1434,6 +1443,7 @@ int edrgp_dbg_syrk_variant(edrgp_ctx* ctx, int64_t N, int M, int variant, int sp
     if (N <= 0 || N % 16 || M % 128 || reps < 1) { set_error("dbg_syrk_variant: need N %% 16 == 0, M %% 128 == 0"); return EDRGP_ERR_INVALID; }
     TRY(c->Knm.reserve((size_t)N * M * sizeof(double)));
     TRY(c->mats[MAT_PHI].reserve(((size_t)M * M + M + 8) * sizeof(double)));
+    c->knm_train_valid = false;
     TRY(fill_pattern(c, c->Knm.d(), (size_t)N * M, splits < 0 ? 0ULL : 12345ULL));   // splits < 0: constant data probe
     if (splits < 0) splits = 0;
     double* Phi = c->mats[MAT_PHI].d();

@@ -179,7 +179,7 @@ int rowdot(Ctx* c, const double* A, const double* B, int64_t rows, int cols, int
 // posterior mean / latent variance / mean Jacobian for one device-resident row chunk
 int predict_chunk(Ctx* c, const KSpec& ks, const double* Xs, int64_t rows, const double* P, const double* Pt,
                   int Mp, const double* wv, const double* winv, double kdiag, double* Kbuf, double* Gbuf,
-                  double* GT, double* mean, double* var, double* jac);
+                  double* GT, double* mean, double* var, double* jac, bool k_ready = false);
 int vec_axpy(Ctx* c, int64_t n, double a, const double* x, double* y);   // y += a x
 
 // ------------------------------------------------------- fp32 row pass (la_gemm32.hip)
@@ -277,6 +277,8 @@ struct Ctx {
     // workspace
     DBuf Knm, W, T;                   // chunk x M
     DBuf mats[16];                    // M x M (or N x N dense) matrices
+    DBuf ptw;                         // -diag(wv) [P | 1 | P.^2] of the RBF predict-gradient path
+    bool knm_train_valid = false;     // c->Knm holds K(X, Z) of ALL training rows for the current theta / Z
     DBuf g2;                          // T^T [X | X.^2] and column sums of T (fused gradient path)
     DBuf slabs, bpart, scal, info, gt_nm, gt_mm, tmpvec[6], panel, trtri_ws, dinv, red;
     std::vector<double> host_scal;

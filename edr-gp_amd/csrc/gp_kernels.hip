@@ -428,12 +428,22 @@ __global__ void var_finish_kernel(double* var, int64_t rows, double kdiag) {
 
 // Posterior mean (K wv), latent variance and mean Jacobian on one row chunk of
 // device-resident test inputs.  Buffers: Kbuf / Gbuf are rows x Mp scratch.
+// Ptw[m][:] = -wv[m] Pt[m][:]   (Mp x Wd)
+__global__ void scale_rows_neg_kernel(const double* __restrict__ Pt, const double* __restrict__ wv, int Mp, int Wd,
+                                      double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < Mp * Wd) out[i] = -wv[i / Wd] * Pt[i];
+}
+
 int predict_chunk(Ctx* c, const KSpec& ks, const double* Xs, int64_t rows, const double* P, const double* Pt,
                   int Mp, const double* wv, const double* winv, double kdiag, double* Kbuf, double* Gbuf,
-                  double* GT, double* mean, double* var, double* jac) {
+                  double* GT, double* mean, double* var, double* jac, bool k_ready) {
     const int D = ks.D;
-    if (mean != nullptr || var != nullptr) {
-        TRY(kernel_matrix(c, ks, Xs, rows, P, Mp, Kbuf, Mp, 0, 0.0, nullptr, nullptr));
+    // RBF: h(r) = -k(r), so the Jacobian's G = wv .* h(r) is K itself with -wv folded into [P | 1 | P.^2]:
+    // no second pass over the pairs (the generic path recomputes the distances on the VALU)
+    const bool rbf1 = (ks.nparts == 1 && ks.kind[0] == EDRGP_KERN_RBF);
+    if (mean != nullptr || var != nullptr || (jac != nullptr && rbf1)) {
+        if (!k_ready) TRY(kernel_matrix(c, ks, Xs, rows, P, Mp, Kbuf, Mp, 0, 0.0, nullptr, nullptr));
         if (mean != nullptr) TRY(gemv_n(c, (int)rows, Mp, 1.0, Kbuf, Mp, wv, mean));
         if (var != nullptr) {
             // quad[n] = sum_m (K Winv)[n][m] K[n][m]
@@ -446,8 +456,15 @@ int predict_chunk(Ctx* c, const KSpec& ks, const double* Xs, int64_t rows, const
     if (jac != nullptr) {
         const int Wd = 2 * D + 1;
         for (int p = 0; p < ks.nparts; ++p) {
-            TRY(hmatrix(c, ks, p, Xs, rows, P, Mp, wv, Gbuf, Mp));
-            TRY(gemm(c, false, false, (int)rows, Wd, Mp, 1.0, Gbuf, Mp, Pt, Wd, 0.0, GT, Wd));
+            if (rbf1) {
+                TRY(c->ptw.reserve((size_t)Mp * Wd * sizeof(double)));
+                hipLaunchKernelGGL(scale_rows_neg_kernel, dim3((Mp * Wd + 255) / 256), dim3(256), 0, c->stream, Pt, wv, Mp,
+                                   Wd, c->ptw.d());
+                TRY(gemm(c, false, false, (int)rows, Wd, Mp, 1.0, Kbuf, Mp, c->ptw.d(), Wd, 0.0, GT, Wd));
+            } else {
+                TRY(hmatrix(c, ks, p, Xs, rows, P, Mp, wv, Gbuf, Mp));
+                TRY(gemm(c, false, false, (int)rows, Wd, Mp, 1.0, Gbuf, Mp, Pt, Wd, 0.0, GT, Wd));
+            }
             const int64_t total = rows * D;
             const int nb = (int)std::min<int64_t>(4096, (total + 255) / 256);
             hipLaunchKernelGGL(jac_finish_kernel, dim3(std::max(nb, 1)), dim3(256), 0, c->stream, Xs, GT, rows, D,

@@ -37,6 +37,14 @@ def projection_sweep(X, y, Z_rows, projections, n_scales=16, kind="RBF", varianc
     h = HipGP(0 if device is None else device) if own else hip
     out = []
     base_sent = False
+    # one chunk for all rows when K_nm fits comfortably (3 N x M fp64 work arrays): one Phi launch per
+    # evaluation and K_nm stays resident for the gradient pass over the training rows
+    Mz = len(Z_rows)
+    if own or 3 * X.shape[0] * Mz * 8 <= 48e9:
+        try:
+            h.set_option("chunk_rows", max(131072, X.shape[0]))
+        except Exception:
+            pass
     X = np.ascontiguousarray(X, dtype=np.float64)
     try:
         for c, W in enumerate(projections):
@@ -66,4 +74,6 @@ def projection_sweep(X, y, Z_rows, projections, n_scales=16, kind="RBF", varianc
     finally:
         if own:
             h.close()
+        else:
+            h.set_option("chunk_rows", 131072)
     return out
