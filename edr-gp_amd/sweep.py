@@ -20,37 +20,22 @@ def length_scale_grid(d, n=16):
     return np.sqrt(d) * 2.0 ** ((np.arange(n) - n // 2) / 4.0)
 
 
-def projection_sweep(X, y, Z_rows, projections, n_scales=16, kind="RBF", variance=1.0, noise=0.01,
-                     rank=0, world_size=1, device=None, want_gradients=False, hip=None, want_gram=False):
-    """Evaluate the Titsias bound (and optionally the posterior-mean gradients at the
-    training rows) for every (projection, length-scale) pair owned by this rank.
-
-    X (N, D), y (N,) standardised; Z_rows: indices of the training rows used as inducing
-    inputs (projected with each candidate); projections: list of (D, d_c) matrices.
-    Returns a list of dicts: candidate, scale index, lengthscale, bound, and (if asked)
-    ``grad`` (N, d_c) and its back-projection ``grad @ W.T`` (N, D), or -- ``want_gram``, the
-    cheap form: the gradients never leave the device -- ``gram`` = grad^T grad (d_c, d_c),
-    ``gsum`` (d_c,) and the back-projected ``gram_full`` = W gram W^T (D, D), whose leading
-    eigenvectors are the EDR directions of that candidate.
-    """
-    own = hip is None
-    h = HipGP(0 if device is None else device) if own else hip
+def _sweep_worker(h, close, X, y, Z_rows, projections, n_scales, kind, variance, noise, rank, world_size,
+                  want_gradients, want_gram, lane, lanes):
+    """One native context working through its share of the (candidate, scale) pairs."""
     out = []
     base_sent = False
-    # one chunk for all rows when K_nm fits comfortably (3 N x M fp64 work arrays): one Phi launch per
-    # evaluation and K_nm stays resident for the gradient pass over the training rows
-    Mz = len(Z_rows)
-    if own or 3 * X.shape[0] * Mz * 8 <= 48e9:
-        try:
-            h.set_option("chunk_rows", max(131072, X.shape[0]))
-        except Exception:
-            pass
-    X = np.ascontiguousarray(X, dtype=np.float64)
+    # one chunk for all rows when K_nm fits comfortably (3 N x M fp64 work arrays per context): one Phi
+    # launch per evaluation and K_nm stays resident for the gradient pass over the training rows
+    big = 3 * X.shape[0] * len(Z_rows) * 8 * lanes <= 96e9
+    if big:
+        h.set_option("chunk_rows", max(131072, X.shape[0]))
     try:
         for c, W in enumerate(projections):
             W = np.asarray(W, dtype=np.float64)
             scales = length_scale_grid(W.shape[1], n_scales)
             mine = [g for g in range(n_scales) if (c * n_scales + g) % world_size == rank]
+            mine = mine[lane::lanes]
             if not mine:
                 continue
             # rows stay resident: a candidate uploads W only and projects on the device
@@ -72,8 +57,52 @@ def projection_sweep(X, y, Z_rows, projections, n_scales=16, kind="RBF", varianc
                     rec["grad_full"] = grad @ W.T
                 out.append(rec)
     finally:
-        if own:
+        if close:
             h.close()
-        else:
+        elif big:
             h.set_option("chunk_rows", 131072)
+    return out
+
+
+def projection_sweep(X, y, Z_rows, projections, n_scales=16, kind="RBF", variance=1.0, noise=0.01,
+                     rank=0, world_size=1, device=None, want_gradients=False, hip=None, want_gram=False,
+                     concurrency=1, hips=None):
+    """Evaluate the Titsias bound (and optionally the posterior-mean gradients at the
+    training rows) for every (projection, length-scale) pair owned by this rank.
+
+    X (N, D), y (N,) standardised; Z_rows: indices of the training rows used as inducing
+    inputs (projected with each candidate); projections: list of (D, d_c) matrices.
+    Returns a list of dicts: candidate, scale index, lengthscale, bound, and (if asked)
+    ``grad`` (N, d_c) and its back-projection ``grad @ W.T`` (N, D), or -- ``want_gram``, the
+    cheap form: the gradients never leave the device -- ``gram`` = grad^T grad (d_c, d_c),
+    ``gsum`` (d_c,) and the back-projected ``gram_full`` = W gram W^T (D, D), whose leading
+    eigenvectors are the EDR directions of that candidate.
+
+    ``concurrency`` > 1: that many native contexts on the same device, each on its own host thread
+    and streams, share the pairs.  One evaluation at M = 1024 spends ~40 % of its time in
+    latency-bound O(M^3) launches that leave the chip almost idle; independent evaluations
+    interleave those with each other's Phi kernels.  (The C ABI is thread-safe across contexts.)
+    """
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    dev = 0 if device is None else device
+    lanes = max(1, int(concurrency))
+    if lanes == 1:
+        own = hip is None
+        h = HipGP(dev) if own else hip
+        out = _sweep_worker(h, own, X, y, Z_rows, projections, n_scales, kind, variance, noise, rank, world_size,
+                            want_gradients, want_gram, 0, 1)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        if hips is not None:                      # caller-owned contexts (one per lane), kept open
+            ctxs, borrowed = list(hips)[:lanes], True
+            lanes = len(ctxs)
+        else:
+            ctxs, borrowed = [hip if (i == 0 and hip is not None) else HipGP(dev if hip is None else hip.device)
+                              for i in range(lanes)], False
+        with ThreadPoolExecutor(max_workers=lanes) as ex:
+            futs = [ex.submit(_sweep_worker, ctxs[i], not borrowed and not (i == 0 and hip is not None), X, y, Z_rows, projections, n_scales,
+                              kind, variance, noise, rank, world_size, want_gradients, want_gram, i, lanes)
+                    for i in range(lanes)]
+            out = [r for f in futs for r in f.result()]
+    out.sort(key=lambda r: (r["candidate"], r["scale"]))
     return out

@@ -71,3 +71,22 @@ def test_sweep_gram_and_device_projection(hip):
     assert abs(recs[4]["bound"] - ref) <= 1e-10 * abs(ref)
     with pytest.raises(ValueError):
         hip.set_data_projected(np.zeros((D + 1, 2)))          # W does not match the resident base rows
+
+
+def test_sweep_concurrent_contexts_match_sequential(hip):
+    """Two native contexts on their own host threads share the (candidate, scale) pairs: same records, same
+    bounds bit for bit (the C ABI is thread-safe across contexts)."""
+    from edrgp_amd.sweep import projection_sweep
+    rng = np.random.default_rng(9)
+    N, D, M = 4000, 10, 96
+    X = rng.standard_normal((N, D))
+    y = np.tanh(X[:, 1]) + 0.05 * rng.standard_normal(N)
+    y = (y - y.mean()) / y.std()
+    projections = [np.linalg.qr(rng.standard_normal((D, D - c)))[0] for c in (0, 4)]
+    Zrows = rng.permutation(N)[:M]
+    seq = projection_sweep(X, y, Zrows, projections, n_scales=5, want_gram=True, hip=hip)
+    par = projection_sweep(X, y, Zrows, projections, n_scales=5, want_gram=True, concurrency=2, device=hip.device)
+    assert [(r["candidate"], r["scale"]) for r in seq] == [(r["candidate"], r["scale"]) for r in par]
+    for a, b in zip(seq, par):
+        assert a["bound"] == b["bound"]
+        assert np.array_equal(a["gram"], b["gram"])
