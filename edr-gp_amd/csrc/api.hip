@@ -697,11 +697,22 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
         TRY(allreduce_sum(c, c->gt_nm.d(), (size_t)np * M * Wd));
         TRY(allreduce_sum(c, sc + SC_DVAR_NM, EDRGP_MAX_PARTS));
     }
-    std::vector<double> g_nm((size_t)np * M * Wd), g_mm((size_t)2 * np * M * Wd), Zh((size_t)M * D);
+    // pinned host staging owned by the context (no per-evaluation allocation / zero-fill; true async copies);
+    // Z itself is the host copy kept by edrgp_set_inducing
+    const size_t n_nm = (size_t)np * M * Wd, n_mm = (size_t)2 * np * M * Wd;
+    if (c->h_stage_cap < n_nm + n_mm) {
+        if (c->h_stage) (void)hipHostFree(c->h_stage);
+        c->h_stage = nullptr;
+        c->h_stage_cap = 0;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_stage), (n_nm + n_mm) * sizeof(double), hipHostMallocDefault));
+        c->h_stage_cap = n_nm + n_mm;
+    }
+    double* g_nm = c->h_stage;
+    double* g_mm = c->h_stage + n_nm;
+    const std::vector<double>& Zh = c->Z_host;
     HIP_TRY(hipMemcpyAsync(h_sc, sc, sizeof(h_sc), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(g_nm.data(), c->gt_nm.d(), g_nm.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(g_mm.data(), c->gt_mm.d(), g_mm.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(Zh.data(), c->Z.d(), Zh.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(g_nm, c->gt_nm.d(), n_nm * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(g_mm, c->gt_mm.d(), n_mm * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     tr.mark("grad D2H queued");
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->drain_events();
@@ -711,6 +722,7 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
     out->dvar.assign(np, 0.0);
     out->dlen.assign((size_t)np * D, 0.0);
     out->dZ.assign((size_t)M * D, 0.0);
+    std::vector<double> s_acc((size_t)D), il2v((size_t)D);
     for (int p = 0; p < np; ++p) {
         out->dvar[p] = h_sc[SC_DVAR_NM + p] + h_sc[SC_DVAR_MM + p] - 0.5 * beta * gl.N;   // + sum dL_dKdiag
         const double* Gn = &g_nm[(size_t)p * M * Wd];
@@ -718,20 +730,27 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
         const double* GmN = &g_mm[(size_t)(2 * p + 1) * M * Wd];
         for (int q = 0; q < D; ++q) {
             const double l = c->lens[(size_t)p * D + q];
-            const double il2 = 1.0 / (l * l), il3 = il2 / l;
-            double s_nm = 0.0, s_mm = 0.0;
-            for (int m = 0; m < M; ++m) {
-                const double z = Zh[(size_t)m * D + q];
-                const double* gn = Gn + (size_t)m * Wd;
-                const double* gt = GmT + (size_t)m * Wd;
-                const double* gN = GmN + (size_t)m * Wd;
-                s_nm += gn[D + 1 + q] + gn[D] * z * z - 2.0 * z * gn[q];
-                s_mm += gt[D + 1 + q] + gt[D] * z * z - 2.0 * z * gt[q];
-                out->dZ[(size_t)m * D + q] +=
-                    il2 * ((z * gn[D] - gn[q]) + (z * gt[D] - gt[q]) + (z * gN[D] - gN[q]));
-            }
-            out->dlen[(size_t)p * D + q] = -il3 * (s_nm + s_mm);
+            il2v[q] = 1.0 / (l * l);
+            s_acc[q] = 0.0;
         }
+        // rows of the M x (2D+1) tables are walked once (m outer, q inner); every per-q sum still runs over
+        // m in ascending order, so the result is the one of the q-outer form
+        for (int m = 0; m < M; ++m) {
+            const double* gn = Gn + (size_t)m * Wd;
+            const double* gt = GmT + (size_t)m * Wd;
+            const double* gN = GmN + (size_t)m * Wd;
+            const double* zr = &Zh[(size_t)m * D];
+            double* dz = &out->dZ[(size_t)m * D];
+            const double cn = gn[D], ct = gt[D], cN = gN[D];
+            for (int q = 0; q < D; ++q) {
+                const double z = zr[q];
+                double s_nm = gn[D + 1 + q] + cn * z * z - 2.0 * z * gn[q];
+                double s_mm = gt[D + 1 + q] + ct * z * z - 2.0 * z * gt[q];
+                s_acc[q] += s_nm + s_mm;
+                dz[q] += il2v[q] * ((z * cn - gn[q]) + (z * ct - gt[q]) + (z * cN - gN[q]));
+            }
+        }
+        for (int q = 0; q < D; ++q) out->dlen[(size_t)p * D + q] = -(il2v[q] / c->lens[(size_t)p * D + q]) * s_acc[q];
     }
     {
         // _compute_dL_dR (homoscedastic); sum(A .* DBi_plus_BiPBi) = M - |LBi|_F^2 + |c|^2 - |u|^2
@@ -975,6 +994,7 @@ int edrgp_ctx_destroy(edrgp_ctx* ctx) {
     for (DBuf* b : {&c->ks_x, &c->ks_z, &c->ks_xn, &c->ks_zn, &c->ks_x2, &c->ks_xn2}) b->release();
     (void)hipEventDestroy(c->ev_fork);
     (void)hipEventDestroy(c->ev_join);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->stream_mm) (void)hipStreamDestroy(c->stream_mm);
     if (c->stream_ms) (void)hipStreamDestroy(c->stream_ms);
     (void)hipStreamDestroy(c->stream2);
@@ -1124,6 +1144,7 @@ int edrgp_set_inducing(edrgp_ctx* ctx, const double* Z, int M) {
     TRY(c->Z.reserve((size_t)M * D * sizeof(double)));
     TRY(c->Zt.reserve((size_t)M * (2 * D + 1) * sizeof(double)));
     HIP_TRY(hipMemcpyAsync(c->Z.d(), Z, (size_t)M * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    c->Z_host.assign(Z, Z + (size_t)M * D);
     TRY(build_xtilde(c, c->Z.d(), M, D, c->Zt.d()));
     HIP_TRY(hipStreamSynchronize(c->stream));   // Z is a borrowed host pointer
     if (c->M != M) c->phi32_bad = false;

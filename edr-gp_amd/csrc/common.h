@@ -282,6 +282,9 @@ struct Ctx {
     DBuf g2;                          // T^T [X | X.^2] and column sums of T (fused gradient path)
     DBuf slabs, bpart, scal, info, gt_nm, gt_mm, tmpvec[6], panel, trtri_ws, dinv, red;
     std::vector<double> host_scal;
+    std::vector<double> Z_host;       // host copy of the inducing inputs (gradient finishing)
+    double* h_stage = nullptr;        // pinned staging of the gradient tables
+    size_t h_stage_cap = 0;
 
     // comm
     void* comm = nullptr;             // ncclComm_t
