@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256) void diag_block_kernel(double* __restrict__ Ab
     __shared__ double Lt[NB][NB + 1];      // Lt[k][i] = L[i][k]
     __shared__ double Tl[4][16][17];       // inverses of the 16x16 diagonal blocks, row-major
     __shared__ double rdiag[NB];           // 1 / L[i][i]
+    __shared__ double Pn[NB][17];          // current 16-column panel, [row][col] (factorisation only)
 #define EDRGP_STAMP(slot) do { if (stamps != nullptr && threadIdx.x == 0) stamps[slot] = __builtin_amdgcn_s_memtime(); } while (0)
     EDRGP_STAMP(0);
     // 4 waves: all of them move data (load, write-back, the four column chains of the inverse); the
@@ -78,36 +79,78 @@ __global__ __launch_bounds__(256) void diag_block_kernel(double* __restrict__ Ab
 
     if (DO_CHOL) {
         if (wave == 0) {
-            double a[NB];                                          // row `lane` of A, then of L
+            // Blocked right-looking factorisation on one wave.  The trailing matrix lives in MFMA C/D tiles
+            // (10 lower 16x16 tiles, reg r of lane l = row (l>>4)+4r, col l&15); only the current 16-column
+            // panel is brought into "row per lane" registers for the 16 serial pivots, and its rank-16 update of
+            // the remaining tiles is 4 MFMAs per tile with both fragments read straight from the [k][row] image
+            // of L in LDS.  (The unblocked form spent ~500 cycles per pivot in LDS broadcast reads of the whole
+            // remaining row; here a pivot touches at most 15 values.)
+            const int lr = lane & 15, lq = lane >> 4;
+            d4 T[4][4];
 #pragma unroll
-            for (int k = 0; k < NB; ++k) a[k] = Lt[k][lane];
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = j; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) T[i][j][r] = Lt[16 * j + lr][16 * i + lq + 4 * r];
             int bad = 0;
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const double p = readlane_f64(a[j], j);
-                if (!(p > 0.0) && bad == 0) bad = info_off + j0 + j + 1;
-                // 1/sqrt(p): v_rsq_f64 + two Newton steps  y <- y (1.5 - 0.5 p y^2)
-                const double hp = 0.5 * p;
-                double y = __builtin_amdgcn_rsq(p);
-                y = y * fma(-hp, y * y, 1.5);
-                y = y * fma(-hp, y * y, 1.5);
-                double l = a[j] * y;                    // lane j: p / sqrt(p) = sqrt(p)
-                if (lane < j) l = 0.0;
-                a[j] = l;
-                if (j + 1 < NB) {
-                    // critical path first: the next pivot needs only l[j+1] (one readlane)
-                    const double cn = readlane_f64(l, j + 1);
-                    a[j + 1] = fma(-l, cn, a[j + 1]);
-                }
-                Lt[j][lane] = l;
-                if (lane == j) rdiag[j] = y;
-                // same-wave LDS write -> read needs no s_barrier (one wave's LDS instructions execute in
-                // order); the wavefront-scope fence only keeps the compiler from hoisting every later
-                // iteration's LDS reads above this point (2000 spilled registers without it)
+            for (int s4 = 0; s4 < 4; ++s4) {
+                // (1) panel s4 (tiles (i, s4), i >= s4) -> one row per lane
+#pragma unroll
+                for (int i = s4; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Pn[16 * i + lq + 4 * r][lr] = T[i][s4][r];
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+                double p[16];
 #pragma unroll
-                for (int k = j + 2; k < NB; ++k) a[k] = fma(-l, Lt[j][k], a[k]);
+                for (int cidx = 0; cidx < 16; ++cidx) p[cidx] = (lane >= 16 * s4) ? Pn[lane][cidx] : 0.0;
+                // (2) the 16 pivots of the panel
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) {
+                    const int j = 16 * s4 + jj;
+                    const double pv = readlane_f64(p[jj], j);
+                    if (!(pv > 0.0) && bad == 0) bad = info_off + j0 + j + 1;
+                    // 1/sqrt(pv): v_rsq_f64 + two Newton steps  y <- y (1.5 - 0.5 pv y^2)
+                    const double hp = 0.5 * pv;
+                    double y = __builtin_amdgcn_rsq(pv);
+                    y = y * fma(-hp, y * y, 1.5);
+                    y = y * fma(-hp, y * y, 1.5);
+                    double l = p[jj] * y;               // lane j: pv / sqrt(pv) = sqrt(pv)
+                    if (lane < j) l = 0.0;
+                    p[jj] = l;
+                    if (jj + 1 < 16) {
+                        // critical path first: the next pivot needs only l[j+1] (one readlane)
+                        const double cn = readlane_f64(l, j + 1);
+                        p[jj + 1] = fma(-l, cn, p[jj + 1]);
+                    }
+                    Lt[j][lane] = l;
+                    if (lane == j) rdiag[j] = y;
+                    // same-wave LDS write -> read: in order, no s_barrier; the fence keeps the compiler from
+                    // hoisting later reads above the store
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int kk = jj + 2; kk < 16; ++kk) p[kk] = fma(-l, Lt[j][16 * s4 + kk], p[kk]);
+                }
+                // (3) rank-16 update of the remaining tiles: T_ib -= P_i P_b^T
+                if (s4 < 3) {
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) {
+                        double af[4], bf[4];
+#pragma unroll
+                        for (int i = s4 + 1; i < 4; ++i) {
+                            bf[i] = Lt[16 * s4 + 4 * st + lq][16 * i + lr];
+                            af[i] = -bf[i];
+                        }
+#pragma unroll
+                        for (int b = s4 + 1; b < 4; ++b)
+#pragma unroll
+                            for (int i = b; i < 4; ++i)
+                                T[i][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[b], T[i][b], 0, 0, 0);
+                    }
+                }
             }
             if (bad && lane == 0 && info != nullptr) atomicCAS(info, 0, bad);
         }
