@@ -39,25 +39,27 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // and report the first non-positive pivot; then (both modes) invert it.  Outputs:
 // the inverse into Dinv (dense 64x64, ld 64, blockIdx-th slab; upper blocks are
 // never written and must be zero) and/or into inv_out (ld ldi, jb x jb part).
+// LDS footprint of the body, in doubles: Lt[64][65] | Tl[4][16][17] | rdiag[64] | Pn[64][17]
+constexpr int DIAG_LDS = NB * (NB + 1) + 4 * 16 * 17 + NB + NB * 17;
+
+// The body is a device function so that the fused Cholesky step kernel can run it on the workgroup that has
+// just finished the next diagonal tile (256 threads, `lds` = DIAG_LDS doubles, uniform call per workgroup).
 template <bool DO_CHOL>
-__global__ __launch_bounds__(256) void diag_block_kernel(double* __restrict__ Abase, int lda, int n,
-                                                        int first_block, double* __restrict__ Dinv,
-                                                        double* __restrict__ inv_out, int ldi,
-                                                        int* __restrict__ info,
-                                                        unsigned long long* __restrict__ stamps,
-                                                        double* __restrict__ Lbase = nullptr, int ldlo = 0,
-                                                        int info_off = 0) {
-    __shared__ double Lt[NB][NB + 1];      // Lt[k][i] = L[i][k]
-    __shared__ double Tl[4][16][17];       // inverses of the 16x16 diagonal blocks, row-major
-    __shared__ double rdiag[NB];           // 1 / L[i][i]
-    __shared__ double Pn[NB][17];          // current 16-column panel, [row][col] (factorisation only)
+__device__ __forceinline__ void diag_block_body(double* __restrict__ Abase, int lda, int n, int blk,
+                                                double* __restrict__ Dinv_slab, double* __restrict__ inv_out, int ldi,
+                                                int* __restrict__ info, unsigned long long* __restrict__ stamps,
+                                                double* __restrict__ Lbase, int ldlo, int info_off,
+                                                double* __restrict__ lds) {
+    double (*Lt)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(lds);                       // Lt[k][i] = L[i][k]
+    double (*Tl)[16][17] = reinterpret_cast<double (*)[16][17]>(lds + NB * (NB + 1));       // inverses of the 16x16 diagonal blocks
+    double* rdiag = lds + NB * (NB + 1) + 4 * 16 * 17;                                      // 1 / L[i][i]
+    double (*Pn)[17] = reinterpret_cast<double (*)[17]>(lds + NB * (NB + 1) + 4 * 16 * 17 + NB);   // current 16-column panel
 #define EDRGP_STAMP(slot) do { if (stamps != nullptr && threadIdx.x == 0) stamps[slot] = __builtin_amdgcn_s_memtime(); } while (0)
     EDRGP_STAMP(0);
     // 4 waves: all of them move data (load, write-back, the four column chains of the inverse); the
     // serial factorisation runs on wave 0 alone, ordered through LDS without barriers (one wave's LDS
     // instructions execute in order).
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int blk = first_block + blockIdx.x;
     const int j0 = blk * NB;
     const int jb = min(NB, n - j0);
     double* A = Abase + (size_t)j0 * lda + j0;
@@ -233,8 +235,8 @@ __global__ __launch_bounds__(256) void diag_block_kernel(double* __restrict__ Ab
         }
     }
     EDRGP_STAMP(4);
-    if (Dinv) {
-        double* D = Dinv + (size_t)blockIdx.x * NB * NB;
+    if (Dinv_slab) {
+        double* D = Dinv_slab;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (i >= j) {
@@ -256,6 +258,20 @@ __global__ __launch_bounds__(256) void diag_block_kernel(double* __restrict__ Ab
     }
     EDRGP_STAMP(5);
 #undef EDRGP_STAMP
+}
+
+template <bool DO_CHOL>
+__global__ __launch_bounds__(256) void diag_block_kernel(double* __restrict__ Abase, int lda, int n,
+                                                        int first_block, double* __restrict__ Dinv,
+                                                        double* __restrict__ inv_out, int ldi,
+                                                        int* __restrict__ info,
+                                                        unsigned long long* __restrict__ stamps,
+                                                        double* __restrict__ Lbase = nullptr, int ldlo = 0,
+                                                        int info_off = 0) {
+    __shared__ __attribute__((aligned(16))) double lds[DIAG_LDS];
+    diag_block_body<DO_CHOL>(Abase, lda, n, first_block + (int)blockIdx.x,
+                             Dinv ? Dinv + (size_t)blockIdx.x * NB * NB : nullptr, inv_out, ldi, info, stamps, Lbase, ldlo,
+                             info_off, lds);
 }
 
 // one factor+invert of a 64x64 block with phase stamps: diagnostic only
@@ -300,10 +316,14 @@ __global__ void fill_kernel(double* __restrict__ A, size_t count, double v) {
 // LDS: the two operand tiles as [row][k] images (stride 66: conflict-free ds_read_b64 per half-wave), reused
 // for L_ik / L_jk; the Dinv fragments (same for both products) sit in registers.
 __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ A, int lda, double* __restrict__ Lout,
-                                                           int ldl, const double* __restrict__ Dinv, int n, int k) {
+                                                           int ldl, const double* __restrict__ Dinv, int n, int k,
+                                                           double* __restrict__ Dinv_next, int* __restrict__ info,
+                                                           int info_off) {
     constexpr int LS = NB + 2;
-    __shared__ __attribute__((aligned(16))) double R1[NB * LS];
-    __shared__ __attribute__((aligned(16))) double R2[NB * LS];
+    static_assert(2 * NB * LS >= DIAG_LDS, "the diagonal-block body reuses the operand tiles' LDS");
+    __shared__ __attribute__((aligned(16))) double Rbuf[2 * NB * LS];
+    double* R1 = Rbuf;
+    double* R2 = Rbuf + NB * LS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lq = lane >> 4;
     int ti, tj;
@@ -420,6 +440,12 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ 
                 const int row = i0 + 32 * wm + 16 * x + lq + 4 * r, col = j0 + 32 * wn + 16 * y + lr;
                 if (row < n && col < n) A[(size_t)row * lda + col] = Cij[x][y][r] - S[x][y][r];
             }
+    // The workgroup of tile (k+1, k+1) has just produced the next diagonal block: factor and invert it here,
+    // so the next step needs no separate (cold, 16 us) diagonal-block launch on the critical path.
+    if (Dinv_next != nullptr && blockIdx.x == 0) {
+        __syncthreads();                 // this workgroup's stores to A are visible to all of its threads
+        diag_block_body<true>(A, lda, n, k + 1, Dinv_next, nullptr, 0, info, nullptr, Lout, ldl, info_off, Rbuf);
+    }
 }
 
 // A = lower triangle of L (explicit zeros above the diagonal)
@@ -434,21 +460,23 @@ __global__ void take_lower_kernel(double* __restrict__ A, int lda, const double*
 static int potrf_lower_fused(Ctx* c, double* A, int n, int lda, int* info_dev, bool reset_info = true,
                              int info_off = 0) {
     if (reset_info) HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), c->stream));
-    if (c->dinv.bytes < (size_t)NB * NB * sizeof(double)) {
-        TRY(c->dinv.reserve((size_t)NB * NB * sizeof(double)));
-        HIP_TRY(hipMemsetAsync(c->dinv.d(), 0, (size_t)NB * NB * sizeof(double), c->stream));
+    if (c->dinv.bytes < (size_t)2 * NB * NB * sizeof(double)) {
+        TRY(c->dinv.reserve((size_t)2 * NB * NB * sizeof(double)));
+        // blocks above the diagonal are never written by the kernel
+        HIP_TRY(hipMemsetAsync(c->dinv.d(), 0, (size_t)2 * NB * NB * sizeof(double), c->stream));
     }
     TRY(c->panel.reserve((size_t)n * n * sizeof(double)));
-    double* Dinv = c->dinv.d();
+    double* Dinv = c->dinv.d();                       // two slabs: step b reads [b & 1] and writes [(b + 1) & 1]
     double* Lw = c->panel.d();
     const int nblk = (n + NB - 1) / NB;
-    for (int b = 0; b < nblk; ++b) {
-        hipLaunchKernelGGL(diag_block_kernel<true>, dim3(1), dim3(256), 0, c->stream, A, lda, n, b, Dinv,
-                           (double*)nullptr, 0, info_dev, (unsigned long long*)nullptr, Lw, n, info_off);
+    hipLaunchKernelGGL(diag_block_kernel<true>, dim3(1), dim3(256), 0, c->stream, A, lda, n, 0, Dinv, (double*)nullptr, 0,
+                       info_dev, (unsigned long long*)nullptr, Lw, n, info_off);
+    for (int b = 0; b + 1 < nblk; ++b) {
         const int r = nblk - b - 1;
-        if (r > 0)
-            hipLaunchKernelGGL(chol_step_kernel, dim3((unsigned)(r * (r + 1) / 2)), dim3(256), 0, c->stream, A, lda, Lw, n,
-                               Dinv, n, b);
+        // one launch per step: panel + trailing update of every tile, and the factor + inverse of the next
+        // diagonal block by the workgroup that has just finished it
+        hipLaunchKernelGGL(chol_step_kernel, dim3((unsigned)(r * (r + 1) / 2)), dim3(256), 0, c->stream, A, lda, Lw, n,
+                           Dinv + (size_t)(b & 1) * NB * NB, n, b, Dinv + (size_t)((b + 1) & 1) * NB * NB, info_dev, info_off);
     }
     dim3 blk(64, 4), grd((n + 63) / 64, (n + 3) / 4);
     hipLaunchKernelGGL(take_lower_kernel, grd, blk, 0, c->stream, A, lda, Lw, n, n);
