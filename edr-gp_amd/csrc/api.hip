@@ -354,6 +354,8 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
     // ---- phase 2: row statistics.  gram: Phi = K^T K, b = K^T y.
     //      stable: Phi := (K Li^T)^T (K Li^T), b := (K Li^T)^T y  (= Li b)
     bool k_resident = false;
+    bool prebuilt = false;             // K_nm (and b) of the single row chunk were built beside phase 1
+    bool kmmi_done = false;            // Kmm^-1 = Li^T Li was formed on the side stream
     // precision 32 asks for the fp32 row pass; it is used while the Gram form is safe in fp32
     // (error ~ eps32 cond(Kmm), judged by the pivot-ratio proxy after phase 1), otherwise this
     // evaluation falls back to the fp64 row pass (last_mode: 1 gram fp64, 2 stable fp64, 3 gram fp32)
@@ -391,7 +393,7 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
             const int64_t r0 = ch * chunk;
             const int64_t rows = std::min<int64_t>(chunk, N - r0);
             double* btarget = (ch == 0) ? bvec : v_tmp;
-            {
+            if (!(prebuilt && ch == 0)) {
                 ProfScope ps(c, EDRGP_PROF_KBUILD);
                 TRY(kernel_matrix(c, ks, c->X.d() + (size_t)r0 * D, rows, c->Z.d(), M, c->Knm.d(), M, 0, 0.0,
                                   stable ? nullptr : c->y.d() + r0, stable ? nullptr : btarget));
@@ -436,6 +438,24 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
             if (st == EDRGP_OK) st = side.join_into_main();
             if (st != EDRGP_OK) return st;
         }
+    } else if (c->overlap && nchunks == 1 && !f32 && c->prebuild) {
+        // Gradient evaluations: the mode (Gram / stable) is only known after phase 1, but K_nm is needed either
+        // way.  Its build (bandwidth / exp-bound) runs on the main stream while the latency-bound phase 1 -- and
+        // Kmm^-1 = Li^T Li for the gradient -- run on the side stream; the Phi kernel then starts alone.
+        {
+            ProfScope ps(c, EDRGP_PROF_KBUILD);
+            TRY(kernel_matrix(c, ks, c->X.d(), N, c->Z.d(), M, c->Knm.d(), M, 0, 0.0, c->y.d(), bvec));
+        }
+        prebuilt = true;
+        SideStream side(c);
+        int st = phase1();
+        if (st == EDRGP_OK && (need_grad || need_post)) {
+            ProfScope ps(c, EDRGP_PROF_SMALL);
+            st = gram_of_lower(c, M, Li, c->mats[MAT_KMMI].d());
+            kmmi_done = (st == EDRGP_OK);
+        }
+        if (st == EDRGP_OK) st = side.join_into_main();
+        if (st != EDRGP_OK) return st;
     } else {
         TRY(phase1());
     }
@@ -542,7 +562,7 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
         HIP_TRY(hipMemsetAsync(R, 0, (size_t)M * M * sizeof(double), c->stream));
         TRY(gemm(c, false, false, M, M, M, 1.0, LBi, M, Li, M, 0.0, R, M, kopt(K_LE_ROW | K_GE_COL, 1)));
         TRY(gram_of_lower(c, M, R, P));
-        TRY(gram_of_lower(c, M, Li, Kmmi));
+        if (!kmmi_done) TRY(gram_of_lower(c, M, Li, Kmmi));
     }
     if (need_post) {
         TRY(c->wv.reserve((size_t)M * sizeof(double)));
@@ -1034,6 +1054,7 @@ int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
     else if (!std::strcmp(key, "kbuild_tile")) c->kbuild_tile = (int)value;
     else if (!std::strcmp(key, "rbf_epilogue")) c->rbf_epilogue = (value != 0.0);
     else if (!std::strcmp(key, "chol_fused")) c->chol_fused = (value != 0.0);
+    else if (!std::strcmp(key, "prebuild")) c->prebuild = (value != 0.0);
     else if (!std::strcmp(key, "syrk_xmap")) c->syrk_xmap = (value != 0.0);
     else if (!std::strcmp(key, "syrk_diag_opt")) c->syrk_diag_opt = (value != 0.0);
     else if (!std::strcmp(key, "mask_layout")) c->mask_layout = (int)value;

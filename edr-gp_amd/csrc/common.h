@@ -221,6 +221,7 @@ struct Ctx {
                                       // 3 = 2 for bound-only evaluations, 1 for gradient evaluations
     bool syrk_diag_opt = true;        // Phi: diagonal tiles compute their 36 lower 16x16 blocks only
     bool syrk_xmap = true;            // Phi: split-major workgroup -> XCD map (la_gemm.hip)
+    bool prebuild = true;             // gradient evaluations: K_nm build on the main stream beside phase 1 on the side stream
     bool chol_fused = true;           // Cholesky: panel + trailing update in one launch per step (la_chol.hip)
     bool rbf_epilogue = true;         // RBF: fused gradient epilogue takes h(r) = -k(r) from the resident K_nm
     bool fuse_grad = true;            // fused Q .* h epilogue of the gradient contraction (single-part kernels, D <= 32)
