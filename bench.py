@@ -68,6 +68,43 @@ def fit_predict_step(h, Z, D, kind, iters):
     h.predict_train(want_mean=True, want_grad=True)
 
 
+def sharding_check(h, dist, rank, world, local_rank):
+    """Row-sharded evaluation (RCCL all-reduce of [Phi | b] and of the gradient partials) against the same
+    problem evaluated whole on rank 0 without a communicator: the relative differences go into the JSON line."""
+    from edrgp_amd.backend import HipGP
+    n, m, d = 4096, 256, 8
+    Xv, yv, Zv = synthetic(n, d, m, seed=77 + rank)
+    ls = np.full((1, d), np.sqrt(d))
+    h.set_data(Xv, yv)
+    h.set_inducing(Zv)
+    h.set_kernel(["RBF"], [1.0], ls, 0.05)
+    got = h.sparse_lml_grad()
+    parts = [None] * world
+    if dist is not None:
+        dist.all_gather_object(parts, (Xv, yv, float(got[0])))
+    else:
+        parts = [(Xv, yv, float(got[0]))]
+    res = None
+    if rank == 0:
+        try:                                   # (local to rank 0: no collective inside, a failure is only reported)
+            h2 = HipGP(local_rank)
+            try:
+                h2.set_data(np.vstack([p[0] for p in parts]), np.concatenate([p[1] for p in parts]))
+                h2.set_inducing(Zv)
+                h2.set_kernel(["RBF"], [1.0], ls, 0.05)
+                ref = h2.sparse_lml_grad()
+            finally:
+                h2.close()
+            rel = lambda a, b: float(np.abs(np.asarray(a) - np.asarray(b)).max() / (np.abs(np.asarray(b)).max() + 1e-300))
+            res = {"rows": n * world, "bound_rel_err": abs(got[0] - ref[0]) / abs(ref[0]),
+                   "grad_rel_err": max(rel(got[1], ref[1]), rel(got[2], ref[2]), abs(got[3] - ref[3]) / abs(ref[3]),
+                                       rel(got[4], ref[4])),
+                   "ranks_agree": len({p[2] for p in parts}) == 1}
+        except Exception as e:                 # noqa: BLE001
+            res = {"error": "%s: %s" % (type(e).__name__, e)}
+    return res
+
+
 def cpu_baseline(N_sample, M, D, kind, iters):
     """The CPU path timed beside the GPU one: the oracle (GPy's LAPACK/BLAS call
     sequence restated in numpy/scipy) on a bounded row sample, all host cores."""
@@ -119,6 +156,7 @@ def main():
     ap.add_argument("--kind", default="RBF")
     ap.add_argument("--iters", type=int, default=ITERS_PER_FIT)
     ap.add_argument("--cpu-sample", type=int, default=4000, help="rows of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--check-sharding", action="store_true", help="run the sharded-vs-whole check (always on for --gpus > 1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -142,6 +180,10 @@ def main():
         box = [HipGP.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         h.comm_init(world, rank, box[0])
+
+    shard_check = None
+    if world > 1 or args.check_sharding:
+        shard_check = sharding_check(h, dist, rank, world, local_rank)
 
     N, M, D = args.N, args.M, args.D
     X, y, Z = synthetic(N, D, M, seed=1000 + rank)
@@ -243,6 +285,8 @@ def main():
             "device_ms_per_step": {"syrk": syrk_ms / args.steps, "grad_gemm": grad_ms / args.steps,
                                    "kernel_build": kb_ms / args.steps, "small_MxM": small_ms / args.steps},
         }
+        if shard_check is not None:
+            out["sharding_check"] = shard_check
         if args.cpu_sample > 0 and world == 1:        # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, M, D, args.kind, args.iters)
         print(json.dumps(out))
