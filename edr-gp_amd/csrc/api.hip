@@ -475,6 +475,8 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
 
     // ---- phase 3: A, B = I + A (jitchol ladder), LB^-1, the M-vectors and scalars
     // no_jitter: return EDRGP_ERR_NOT_PD at the first failed factorisation instead of climbing the ladder
+    // the fused one-launch-per-step factorisation covers n in (64, 3072]; outside it the explicit inverse stays
+    const bool rhs_row = !need_grad && !need_post && c->chol_rhs && c->chol_fused && M > 64 && M + 1 <= 3072;
     auto phase3 = [&](bool no_jitter) -> int {
       for (int lvl = -1;;) {
         ProfScope ps(c, EDRGP_PROF_SMALL);
@@ -490,9 +492,30 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
             TRY(gemv_n(c, M, M, 1.0, Li, M, bvec, v_v));
         }
         TRY(trace_of(c, A, M, M, sc + SC_TRA));
+        const double bjit = 1.0 + (lvl >= 0 ? jit_amount(lvl, 1.0 + h_sc[SC_TRA] / M) : 0.0);
+        if (rhs_row) {
+            // bound only: the bound needs |c|^2, c = beta LB^-1 v, and log det LB, not LB^-1.  beta v rides
+            // through the factorisation as row M of the (M+1) x (M+1) matrix [[B, .], [beta v^T, alpha]]: the
+            // panel steps turn it into c^T (forward substitution by the trailing updates), one extra step
+            // instead of the explicit inverse (10 launches) and its products
+            const int ldb = M + 8;
+            TRY(c->lbaug.reserve((size_t)(M + 1) * ldb * sizeof(double)));
+            double* Lg = c->lbaug.d();
+            HIP_TRY(hipMemcpy2DAsync(Lg, (size_t)ldb * sizeof(double), A, (size_t)M * sizeof(double),
+                                     (size_t)M * sizeof(double), (size_t)M, hipMemcpyDeviceToDevice, c->stream));
+            TRY(add_diag(c, Lg, M, ldb, bjit));
+            TRY(aug_rhs_row(c, Lg + (size_t)M * ldb, v_v, M, beta));
+            TRY(potrf_lower(c, Lg, M + 1, ldb, info + 1));
+            TRY(sum_log_diag(c, Lg, M, ldb, sc + SC_SUMLOGLB));
+            TRY(sum_sq(c, Lg + (size_t)M * ldb, M, sc + SC_DATAFIT));
+            if (f32) {
+                TRY(diag_minmax(c, Lg, M, ldb, sc + SC_LBDIAGMIN));
+                TRY(frob_sq(c, Phi, M, M, sc + SC_PHIFROB));
+            }
+        } else {
         HIP_TRY(hipMemcpyAsync(LB, A, (size_t)M * M * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         // jitter on B: mean(diag(B)) = 1 + trA / M, trA known from the failed pass
-        TRY(add_diag(c, LB, M, M, 1.0 + (lvl >= 0 ? jit_amount(lvl, 1.0 + h_sc[SC_TRA] / M) : 0.0)));
+        TRY(add_diag(c, LB, M, M, bjit));
         TRY(potrf_lower(c, LB, M, M, info + 1));
         TRY(trtri_lower(c, LB, M, LBi, M, M));
         TRY(sum_log_diag(c, LB, M, M, sc + SC_SUMLOGLB));
@@ -506,6 +529,7 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
         if (f32) {
             TRY(diag_minmax(c, LB, M, M, sc + SC_LBDIAGMIN));
             TRY(frob_sq(c, Phi, M, M, sc + SC_PHIFROB));
+        }
         }
         HIP_TRY(hipMemcpyAsync(h_sc, sc, sizeof(h_sc), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(h_info, info, sizeof(h_info), hipMemcpyDeviceToHost, c->stream));
@@ -1054,6 +1078,7 @@ int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
     else if (!std::strcmp(key, "kbuild_tile")) c->kbuild_tile = (int)value;
     else if (!std::strcmp(key, "rbf_epilogue")) c->rbf_epilogue = (value != 0.0);
     else if (!std::strcmp(key, "chol_fused")) c->chol_fused = (value != 0.0);
+    else if (!std::strcmp(key, "chol_rhs")) c->chol_rhs = (value != 0.0);
     else if (!std::strcmp(key, "prebuild")) c->prebuild = (value != 0.0);
     else if (!std::strcmp(key, "syrk_xmap")) c->syrk_xmap = (value != 0.0);
     else if (!std::strcmp(key, "syrk_diag_opt")) c->syrk_diag_opt = (value != 0.0);

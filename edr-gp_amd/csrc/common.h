@@ -147,6 +147,7 @@ int diag_block_stamps(Ctx* c, double* A64, double* Dinv64, unsigned long long* s
 int gemv_n(Ctx* c, int M, int N, double alpha, const double* A, int lda, const double* x, double* y);
 int gemv_t(Ctx* c, int M, int N, double alpha, const double* A, int lda, const double* x, double* y);
 int add_diag(Ctx* c, double* A, int n, int lda, double v);
+int aug_rhs_row(Ctx* c, double* row, const double* v, int n, double scale);   // row = scale v, row[n] = 1 + |row|^2
 int sum_sq(Ctx* c, const double* x, int64_t n, double* out);               // out[0] = sum x^2
 int dot(Ctx* c, const double* x, const double* y, int64_t n, double* out);
 int trace_of(Ctx* c, const double* A, int n, int lda, double* out);
@@ -222,6 +223,7 @@ struct Ctx {
     bool syrk_diag_opt = true;        // Phi: diagonal tiles compute their 36 lower 16x16 blocks only
     bool syrk_xmap = true;            // Phi: split-major workgroup -> XCD map (la_gemm.hip)
     bool prebuild = true;             // gradient evaluations: K_nm build on the main stream beside phase 1 on the side stream
+    bool chol_rhs = true;             // bound-only evaluations: L_B^-1 (beta v) as an extra row of the factorisation, no explicit L_B^-1
     bool chol_fused = true;           // Cholesky: panel + trailing update in one launch per step (la_chol.hip)
     bool rbf_epilogue = true;         // RBF: fused gradient epilogue takes h(r) = -k(r) from the resident K_nm
     bool fuse_grad = true;            // fused Q .* h epilogue of the gradient contraction (single-part kernels, D <= 32)
@@ -281,7 +283,7 @@ struct Ctx {
     DBuf ptw;                         // -diag(wv) [P | 1 | P.^2] of the RBF predict-gradient path
     bool knm_train_valid = false;     // c->Knm holds K(X, Z) of ALL training rows for the current theta / Z
     DBuf g2;                          // T^T [X | X.^2] and column sums of T (fused gradient path)
-    DBuf slabs, bpart, scal, info, gt_nm, gt_mm, tmpvec[6], panel, trtri_ws, dinv, red;
+    DBuf slabs, bpart, scal, info, gt_nm, gt_mm, tmpvec[6], panel, trtri_ws, dinv, red, lbaug;
     std::vector<double> host_scal;
     std::vector<double> Z_host;       // host copy of the inducing inputs (gradient finishing)
     double* h_stage = nullptr;        // pinned staging of the gradient tables

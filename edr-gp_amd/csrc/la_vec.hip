@@ -110,6 +110,34 @@ int add_diag(Ctx* c, double* A, int n, int lda, double v) {
     return EDRGP_OK;
 }
 
+// Right-hand side carried through a Cholesky factorisation as one extra matrix row:
+//   row[j] = scale v[j] (j < n),   row[n] = 1 + sum_j row[j]^2
+// Factoring [[B, .], [row, row[n]]] leaves L^-1 (scale v) in that row; with lambda_min(B) >= 1 the last
+// pivot row[n] - |L^-1 scale v|^2 stays >= 1.  One workgroup, fixed summation order.
+__global__ __launch_bounds__(256) void aug_rhs_row_kernel(double* __restrict__ row, const double* __restrict__ v, int n,
+                                                          double scale) {
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const double t = scale * v[i];
+        row[i] = t;
+        s = fma(t, t, s);
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) row[n] = 1.0 + sh[0];
+}
+
+int aug_rhs_row(Ctx* c, double* row, const double* v, int n, double scale) {
+    hipLaunchKernelGGL(aug_rhs_row_kernel, dim3(1), dim3(256), 0, c->stream, row, v, n, scale);
+    HIP_TRY(hipGetLastError());
+    return EDRGP_OK;
+}
+
 // Generic single-block reduction with a fixed order: mode selects the summand.
 //  0: x[i]^2   1: x[i]*y[i]   2: A[i][i]   3: log(A[i][i])   4: A[i][i]/n
 __global__ __launch_bounds__(256) void reduce1_kernel(int mode, const double* __restrict__ x,

@@ -158,6 +158,31 @@ def test_sparse_chunked_rows_equal_unchunked(hip):
         assert np.abs(r[4] - dZ).max() <= 1e-7 * np.abs(dZ).max()
 
 
+@pytest.mark.parametrize("N,M,D,mode", [(900, 65, 3, 0), (1500, 130, 6, 0), (2500, 192, 5, 2), (4000, 449, 9, 0)])
+def test_bound_only_rhs_row_equals_explicit_inverse(hip, N, M, D, mode):
+    """Bound-only evaluations carry beta*v through the second factorisation as an extra matrix row (M + 1
+    rows, ragged last block) instead of forming L_B^-1: same bound as the explicit form and as the oracle."""
+    X, y, Z = go.synthetic_problem(N, D, M, seed=N + M)
+    kern = go.make_kernel(["RBF"], D, [dict(variance=1.1, lengthscale=1.5 * np.sqrt(D))])
+    hip.set_data(X, y)
+    hip.set_inducing(Z)
+    set_kernel(hip, kern, 0.04)
+    hip.set_option("stats_mode", mode)
+    try:
+        hip.set_option("chol_rhs", 0)
+        explicit = hip.sparse_lml()
+        hip.set_option("chol_rhs", 1)
+        row = hip.sparse_lml()
+        again = hip.sparse_lml()
+    finally:
+        hip.set_option("chol_rhs", 1)
+        hip.set_option("stats_mode", 0)
+    ref = go.vardtc_inference(kern, X, Z, 0.04, y[:, None])["log_marginal"][0, 0]
+    assert row == again
+    assert abs(row - explicit) <= 1e-12 * abs(explicit)
+    assert abs(row - ref) <= 1e-10 * abs(ref)
+
+
 def test_sparse_jitchol_retry_duplicate_inducing(hip):
     """Z with exact duplicates: Kmm + 1e-8 I is numerically singular for a wide RBF;
     the jitter ladder (GPy jitchol) must take over or succeed; result must be finite."""
