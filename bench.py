@@ -278,8 +278,9 @@ def main():
                          "avg_launch_ms": avg_ms, "launches": syrk_n, "flops_per_launch": flops_per_launch,
                          "peak_source": "AMD public MI355X fp64 matrix spec (not in the local guide)",
                          "peak_calibrated_tflops": calib_tf,
-                         "note": "achieved = launches inside the timed region, where the O(M^3) phase runs beside this "
-                                 "kernel on a side stream; isolated = the same kernel alone (its slab reduction included)",
+                         "note": "achieved = HIP events around the launches inside the timed region (the kernel has the GPU to "
+                                 "itself: the O(M^3) phase 1 overlaps the K_nm build, not this kernel); isolated = the same "
+                                 "kernel alone (its slab reduction included)",
                          "isolated_ms": iso_ms,
                          "isolated_tflops": (flops_per_launch / (iso_ms * 1e-3) * 1e-12) if iso_ms else None},
             "device_ms_per_step": {"syrk": syrk_ms / args.steps, "grad_gemm": grad_ms / args.steps,

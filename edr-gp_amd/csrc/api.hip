@@ -423,9 +423,12 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
     // (Gram form: A = beta Li (K^T K) Li^T, rounding error ~ eps cond(Kmm);
     //  stable form: A = beta (K Li^T)^T (K Li^T), error ~ eps sqrt(cond).)
     tr.mark("setup");
-    // level 3 (default): bound-only evaluations overlap phase 1 (worth 5 % there); gradient evaluations
-    // keep the row pass alone on the GPU and use the side stream for the Kmm gradient term only
-    const bool want_p1 = (c->overlap == 2) || (c->overlap == 3 && !need_grad);
+    // level 3 (default): with one resident chunk, the K_nm build runs beside phase 1 and the Phi kernel keeps
+    // the GPU to itself (Cm bound-only: 10.4 ms; the whole row pass beside phase 1: 10.9 ms, the Phi kernel
+    // stretched from 6.6 to 8.2 ms by the side stream's 70 launches; no overlap: 10.8 ms).  Chunked row passes of
+    // bound-only evaluations overlap phase 1 with the whole pass.  Level 2 forces the latter everywhere.
+    const bool can_prebuild = c->overlap && nchunks == 1 && !f32 && c->prebuild;
+    const bool want_p1 = (c->overlap == 2) || (c->overlap == 3 && !need_grad && !can_prebuild);
     // bound-only evaluations (default policy): masked stream pair, phase 1 gets its own CUs
     MaskedScope masked(c, c->overlap == 3 && !need_grad && c->side_cus > 0 && !c->comm && ensure_masked_streams(c));
     const bool optimistic = want_p1 && (c->stats_mode == 1 || (c->stats_mode == 0 && c->last_mode != 2));
@@ -438,8 +441,8 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
             if (st == EDRGP_OK) st = side.join_into_main();
             if (st != EDRGP_OK) return st;
         }
-    } else if (c->overlap && nchunks == 1 && !f32 && c->prebuild) {
-        // Gradient evaluations: the mode (Gram / stable) is only known after phase 1, but K_nm is needed either
+    } else if (can_prebuild) {
+        // The mode (Gram / stable) is only known after phase 1, but K_nm is needed either
         // way.  Its build (bandwidth / exp-bound) runs on the main stream while the latency-bound phase 1 -- and
         // Kmm^-1 = Li^T Li for the gradient -- run on the side stream; the Phi kernel then starts alone.
         {
