@@ -299,10 +299,21 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
         set_error("sparse evaluation needs set_data, set_inducing and set_kernel first");
         return EDRGP_ERR_STATE;
     }
-    const int M = c->M, D = c->D;
+    const int D = c->D;
     const int64_t N = c->N;
     const int Wd = 2 * D + 1;
     const int np = c->nparts;
+    // Working size.  The matrix kernels run their fast paths on whole 128-wide tiles and whole k-tiles only
+    // (M = 1000 ran 1.4x slower than M = 1024).  An inducing set whose size is not a multiple of 128 is therefore
+    // embedded in the next multiple: Mr real points plus M - Mr phantom points that are decoupled from
+    // everything -- K_nm gets zero columns, Kmm the block [[Kmm, 0], [0, I]].  Then Lm, Lm^-1, B, LB, LB^-1,
+    // Kmm^-1, P are block diagonal with an identity block, Phi / A / S2 / dL/dKmm have zero phantom blocks, and
+    // the bound and every gradient of the real parameters are those of the Mr-point problem (the log-determinants
+    // gain log 1, the traces 0).  Only the builds know about Mr; everything between them works on M.
+    const int Mr = c->M;
+    const bool padded = c->pad_inducing && Mr > 256 && (Mr % 128) != 0 && c->precision != 32;
+    const int M = padded ? (Mr + 127) / 128 * 128 : Mr;
+    c->M_work = M;
     c->knm_train_valid = false;
     const double beta = 1.0 / std::max(c->noise_var, 1e-8);
     const KSpec ks = make_kspec(c);
@@ -312,7 +323,8 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
     TRY(ensure_mats(c, M, need_grad ? 14 : (need_post ? 10 : 7)));
     const int64_t chunk = std::min<int64_t>(N, std::max<int64_t>(64, c->chunk_rows));
     const int64_t nchunks = (N + chunk - 1) / chunk;
-    TRY(c->Knm.reserve((size_t)chunk * M * sizeof(double)));
+    // 16 spare rows: the row count handed to the Phi kernel is rounded up to whole k-tiles with zero rows
+    TRY(c->Knm.reserve((size_t)(chunk + 16) * M * sizeof(double)));
     double* Lm = c->mats[MAT_LM].d();
     double* Li = c->mats[MAT_LI].d();
     double* Phi = c->mats[MAT_PHI].d();
@@ -337,10 +349,12 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
     auto phase1 = [&]() -> int {
         for (int lvl = -1;;) {
             ProfScope ps(c, EDRGP_PROF_SMALL);
-            TRY(kernel_matrix(c, ks, c->Z.d(), M, c->Z.d(), M, Lm, M, 1, 1e-8 + jit_amount(lvl, kmm_diag_mean),
+            if (padded) HIP_TRY(hipMemsetAsync(Lm, 0, (size_t)M * M * sizeof(double), c->stream));
+            TRY(kernel_matrix(c, ks, c->Z.d(), Mr, c->Z.d(), Mr, Lm, M, 1, 1e-8 + jit_amount(lvl, kmm_diag_mean),
                               nullptr, nullptr));
+            if (padded) TRY(add_diag(c, Lm + (size_t)Mr * M + Mr, M - Mr, M, 1.0));
             TRY(potrf_lower(c, Lm, M, M, info + 0));
-            TRY(diag_minmax(c, Lm, M, M, sc + SC_DIAGMIN));
+            TRY(diag_minmax(c, Lm, Mr, M, sc + SC_DIAGMIN));
             HIP_TRY(hipMemcpyAsync(h_sc, sc, sizeof(h_sc), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipMemcpyAsync(h_info, info, sizeof(h_info), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
@@ -368,6 +382,16 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
     bool g32 = want32 && need_grad && D <= 64;      // and a Kmm conditioned for the Gram form, decided after phase 1
     bool f32 = want32 && c->f32_phi && !c->phi32_bad;
     bool k32_resident = false;
+    // K(X[r0 : r0 + rows], Z) into `out` (ld M) and, when yv is given, K^T yv into bt; phantom columns are zero
+    auto build_knm = [&](int64_t r0, int64_t rows, double* outK, const double* yv, double* bt) -> int {
+        TRY(kernel_matrix(c, ks, c->X.d() + (size_t)r0 * D, rows, c->Z.d(), Mr, outK, M, 0, 0.0, yv, bt));
+        if (padded) {
+            HIP_TRY(hipMemset2DAsync(outK + Mr, (size_t)M * sizeof(double), 0, (size_t)(M - Mr) * sizeof(double), (size_t)rows,
+                                     c->stream));
+            if (bt != nullptr) HIP_TRY(hipMemsetAsync(bt + Mr, 0, (size_t)(M - Mr) * sizeof(double), c->stream));
+        }
+        return EDRGP_OK;
+    };
     auto phase2 = [&](bool stable) -> int {
         if (f32) {
             // fp32 row pass: K_nm stored and multiplied in fp32, Phi / b accumulated into fp64
@@ -388,15 +412,14 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
             if (c->comm) TRY(allreduce_sum(c, Phi, (size_t)M * M + M));
             return EDRGP_OK;
         }
-        if (stable) TRY(c->W.reserve((size_t)chunk * M * sizeof(double)));
+        if (stable) TRY(c->W.reserve((size_t)(chunk + 16) * M * sizeof(double)));
         for (int64_t ch = 0; ch < nchunks; ++ch) {
             const int64_t r0 = ch * chunk;
             const int64_t rows = std::min<int64_t>(chunk, N - r0);
             double* btarget = (ch == 0) ? bvec : v_tmp;
             if (!(prebuilt && ch == 0)) {
                 ProfScope ps(c, EDRGP_PROF_KBUILD);
-                TRY(kernel_matrix(c, ks, c->X.d() + (size_t)r0 * D, rows, c->Z.d(), M, c->Knm.d(), M, 0, 0.0,
-                                  stable ? nullptr : c->y.d() + r0, stable ? nullptr : btarget));
+                TRY(build_knm(r0, rows, c->Knm.d(), stable ? nullptr : c->y.d() + r0, stable ? nullptr : btarget));
             }
             const double* S = c->Knm.d();
             if (stable) {
@@ -407,10 +430,16 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
                 S = c->W.d();
             }
             if (ch > 0) TRY(vec_axpy(c, M, 1.0, v_tmp, bvec));
-            TRY(syrk_tn(c, S, rows, M, M, Phi, M, ch > 0));
+            // whole k-tiles for the Phi kernel (its 16-byte loaders and the paired diagonal tiles need them):
+            // zero rows add nothing to K^T K
+            const int64_t rows_pad = (rows + 15) & ~(int64_t)15;
+            if (rows_pad > rows)
+                HIP_TRY(hipMemsetAsync(const_cast<double*>(S) + (size_t)rows * M, 0, (size_t)(rows_pad - rows) * M * sizeof(double),
+                                       c->stream));
+            TRY(syrk_tn(c, S, rows_pad, M, M, Phi, M, ch > 0));
         }
         k_resident = (nchunks == 1);
-        c->knm_train_valid = k_resident;          // (the stable form keeps K_nm in Knm and K_nm Li^T in W)
+        c->knm_train_valid = k_resident && !padded;          // predictions address K_nm with ld = number of real points          // (the stable form keeps K_nm in Knm and K_nm Li^T in W)
         if (c->comm) TRY(allreduce_sum(c, Phi, (size_t)M * M + M));
         return EDRGP_OK;
     };
@@ -447,7 +476,7 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
         // Kmm^-1 = Li^T Li for the gradient -- run on the side stream; the Phi kernel then starts alone.
         {
             ProfScope ps(c, EDRGP_PROF_KBUILD);
-            TRY(kernel_matrix(c, ks, c->X.d(), N, c->Z.d(), M, c->Knm.d(), M, 0, 0.0, c->y.d(), bvec));
+            TRY(build_knm(0, N, c->Knm.d(), c->y.d(), bvec));
         }
         prebuilt = true;
         SideStream side(c);
@@ -495,7 +524,7 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
             TRY(gemv_n(c, M, M, 1.0, Li, M, bvec, v_v));
         }
         TRY(trace_of(c, A, M, M, sc + SC_TRA));
-        const double bjit = 1.0 + (lvl >= 0 ? jit_amount(lvl, 1.0 + h_sc[SC_TRA] / M) : 0.0);
+        const double bjit = 1.0 + (lvl >= 0 ? jit_amount(lvl, 1.0 + h_sc[SC_TRA] / Mr) : 0.0);
         if (rhs_row) {
             // bound only: the bound needs |c|^2, c = beta LB^-1 v, and log det LB, not LB^-1.  beta v rides
             // through the factorisation as row M of the (M+1) x (M+1) matrix [[B, .], [beta v^T, alpha]]: the
@@ -592,13 +621,20 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
         if (!kmmi_done) TRY(gram_of_lower(c, M, Li, Kmmi));
     }
     if (need_post) {
-        TRY(c->wv.reserve((size_t)M * sizeof(double)));
-        TRY(c->winv.reserve((size_t)M * M * sizeof(double)));
-        HIP_TRY(hipMemcpyAsync(c->wv.d(), v_wv, (size_t)M * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-        TRY(combine3(c, M, 1.0, Kmmi, -1.0, P, 0.0, nullptr, 0.0, nullptr, c->winv.d()));
+        // the posterior is kept compact: Mr entries of wv, the Mr x Mr block of Kmm^-1 - P
+        TRY(c->wv.reserve((size_t)Mr * sizeof(double)));
+        TRY(c->winv.reserve((size_t)Mr * Mr * sizeof(double)));
+        HIP_TRY(hipMemcpyAsync(c->wv.d(), v_wv, (size_t)Mr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        if (padded) {
+            TRY(combine3(c, M, 1.0, Kmmi, -1.0, P, 0.0, nullptr, 0.0, nullptr, Tm));        // Tm is free here
+            HIP_TRY(hipMemcpy2DAsync(c->winv.d(), (size_t)Mr * sizeof(double), Tm, (size_t)M * sizeof(double),
+                                     (size_t)Mr * sizeof(double), (size_t)Mr, hipMemcpyDeviceToDevice, c->stream));
+        } else {
+            TRY(combine3(c, M, 1.0, Kmmi, -1.0, P, 0.0, nullptr, 0.0, nullptr, c->winv.d()));
+        }
         c->have_post = true;
         c->post_dense = false;
-        c->P = M;
+        c->P = Mr;
     }
     if (!need_grad) {
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -686,8 +722,7 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
         const int64_t rows = std::min<int64_t>(chunk, N - r0);
         if (!k_resident) {
             ProfScope ps(c, EDRGP_PROF_KBUILD);
-            TRY(kernel_matrix(c, ks, c->X.d() + (size_t)r0 * D, rows, c->Z.d(), M, c->Knm.d(), M, 0, 0.0, nullptr,
-                              nullptr));
+            TRY(build_knm(r0, rows, c->Knm.d(), nullptr, nullptr));
         }
         // the distance-recomputing epilogue stages D <= 32 features; the RBF epilogue reads k from K_nm: any D
         const bool fused = (np == 1) && c->fuse_grad &&
@@ -768,7 +803,7 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
     // ---- finishing on the host: O(M D) arithmetic
     out->dvar.assign(np, 0.0);
     out->dlen.assign((size_t)np * D, 0.0);
-    out->dZ.assign((size_t)M * D, 0.0);
+    out->dZ.assign((size_t)Mr * D, 0.0);
     std::vector<double> s_acc((size_t)D), il2v((size_t)D);
     for (int p = 0; p < np; ++p) {
         out->dvar[p] = h_sc[SC_DVAR_NM + p] + h_sc[SC_DVAR_MM + p] - 0.5 * beta * gl.N;   // + sum dL_dKdiag
@@ -782,7 +817,7 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
         }
         // rows of the M x (2D+1) tables are walked once (m outer, q inner); every per-q sum still runs over
         // m in ascending order, so the result is the one of the q-outer form
-        for (int m = 0; m < M; ++m) {
+        for (int m = 0; m < Mr; ++m) {            // phantom rows of the tables are zero
             const double* gn = Gn + (size_t)m * Wd;
             const double* gt = GmT + (size_t)m * Wd;
             const double* gN = GmN + (size_t)m * Wd;
@@ -1082,6 +1117,7 @@ int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
     else if (!std::strcmp(key, "rbf_epilogue")) c->rbf_epilogue = (value != 0.0);
     else if (!std::strcmp(key, "chol_fused")) c->chol_fused = (value != 0.0);
     else if (!std::strcmp(key, "chol_rhs")) c->chol_rhs = (value != 0.0);
+    else if (!std::strcmp(key, "pad_inducing")) c->pad_inducing = (value != 0.0);
     else if (!std::strcmp(key, "prebuild")) c->prebuild = (value != 0.0);
     else if (!std::strcmp(key, "syrk_xmap")) c->syrk_xmap = (value != 0.0);
     else if (!std::strcmp(key, "syrk_diag_opt")) c->syrk_diag_opt = (value != 0.0);
@@ -1190,13 +1226,18 @@ int edrgp_set_inducing(edrgp_ctx* ctx, const double* Z, int M) {
     if (!Z || M <= 0) { set_error("set_inducing: bad M=%d", M); return EDRGP_ERR_INVALID; }
     if (!c->have_data) { set_error("set_inducing: call set_data first (fixes D)"); return EDRGP_ERR_STATE; }
     const int D = c->D;
-    TRY(c->Z.reserve((size_t)M * D * sizeof(double)));
-    TRY(c->Zt.reserve((size_t)M * (2 * D + 1) * sizeof(double)));
+    // rows up to the next multiple of 128 stay zero: coordinates of the phantom points of a padded evaluation
+    const size_t Mcap = ((size_t)M + 127) / 128 * 128;
+    TRY(c->Z.reserve(Mcap * D * sizeof(double)));
+    TRY(c->Zt.reserve(Mcap * (2 * D + 1) * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(c->Z.d(), 0, Mcap * D * sizeof(double), c->stream));
+    HIP_TRY(hipMemsetAsync(c->Zt.d(), 0, Mcap * (2 * D + 1) * sizeof(double), c->stream));
     HIP_TRY(hipMemcpyAsync(c->Z.d(), Z, (size_t)M * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
     c->Z_host.assign(Z, Z + (size_t)M * D);
     TRY(build_xtilde(c, c->Z.d(), M, D, c->Zt.d()));
     HIP_TRY(hipStreamSynchronize(c->stream));   // Z is a borrowed host pointer
     if (c->M != M) c->phi32_bad = false;
+    c->M_work = 0;
     c->knm_train_valid = false;
     c->M = M;
     c->have_Z = true;
@@ -1332,18 +1373,22 @@ int edrgp_get(edrgp_ctx* ctx, int which, double* buf, int64_t cap) {
     CTX(ctx);
     if (!buf) return EDRGP_ERR_INVALID;
     const size_t M = (size_t)c->M;
+    // the last sparse evaluation may have worked on a padded inducing set (ld Mw): the caller gets the real block
+    const size_t Mw = (c->M_work >= c->M) ? (size_t)c->M_work : M;
     const double* src = nullptr;
     size_t n = 0;
+    size_t rows2d = 0;          // > 0: rows2d x M block of an ld-Mw matrix
     switch (which) {
-        case EDRGP_GET_PHI: src = c->mats[MAT_PHI].d(); n = M * M; break;
-        case EDRGP_GET_BVEC: src = c->mats[MAT_PHI].d() ? c->mats[MAT_PHI].d() + M * M : nullptr; n = M; break;
-        case EDRGP_GET_LM: case EDRGP_GET_KMM: src = c->mats[MAT_LM].d(); n = M * M; break;
-        case EDRGP_GET_LB: src = c->mats[MAT_LB].d(); n = M * M; break;
-        case EDRGP_GET_A: src = c->mats[MAT_A].d(); n = M * M; break;
+        case EDRGP_GET_PHI: src = c->mats[MAT_PHI].d(); n = M * M; rows2d = M; break;
+        case EDRGP_GET_BVEC: src = c->mats[MAT_PHI].d() ? c->mats[MAT_PHI].d() + Mw * Mw : nullptr; n = M; break;
+        case EDRGP_GET_LM: case EDRGP_GET_KMM: src = c->mats[MAT_LM].d(); n = M * M; rows2d = M; break;
+        case EDRGP_GET_LB: src = c->mats[MAT_LB].d(); n = M * M; rows2d = M; break;
+        case EDRGP_GET_A: src = c->mats[MAT_A].d(); n = M * M; rows2d = M; break;
         case EDRGP_GET_WV: src = c->wv.d(); n = (size_t)c->P; break;
         case EDRGP_GET_WINV: src = c->winv.d(); n = (size_t)c->P * c->P; break;
         case EDRGP_GET_KNM:
-            n = (size_t)std::min<int64_t>(c->N, c->chunk_rows) * M;
+            rows2d = (size_t)std::min<int64_t>(c->N, c->chunk_rows);
+            n = rows2d * M;
             if (c->last_mode == 3) {          // fp32 row pass: widen the resident chunk
                 if ((int64_t)n > cap) { set_error("edrgp_get: buffer too small"); return EDRGP_ERR_INVALID; }
                 std::vector<float> tmp(n);
@@ -1354,9 +1399,9 @@ int edrgp_get(edrgp_ctx* ctx, int which, double* buf, int64_t cap) {
             }
             src = c->Knm.d();
             break;
-        case EDRGP_GET_LMI: src = c->mats[MAT_LI].d(); n = M * M; break;
-        case EDRGP_GET_LBI: src = c->mats[MAT_LBI].d(); n = M * M; break;
-        case EDRGP_GET_DLDKMM: src = c->mats[MAT_DKMM].d(); n = M * M; break;
+        case EDRGP_GET_LMI: src = c->mats[MAT_LI].d(); n = M * M; rows2d = M; break;
+        case EDRGP_GET_LBI: src = c->mats[MAT_LBI].d(); n = M * M; rows2d = M; break;
+        case EDRGP_GET_DLDKMM: src = c->mats[MAT_DKMM].d(); n = M * M; rows2d = M; break;
         case EDRGP_GET_SCALARS: src = c->scal.d(); n = 16; break;
         case EDRGP_GET_MODE:
             buf[0] = (double)c->last_mode;
@@ -1368,7 +1413,10 @@ int edrgp_get(edrgp_ctx* ctx, int which, double* buf, int64_t cap) {
     if (!src) { set_error("edrgp_get: object %d not computed yet", which); return EDRGP_ERR_STATE; }
     if ((int64_t)n > cap) { set_error("edrgp_get: buffer too small (%lld < %zu)", (long long)cap, n); return EDRGP_ERR_INVALID; }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(buf, src, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (rows2d > 0 && Mw != M)
+        HIP_TRY(hipMemcpy2D(buf, M * sizeof(double), src, Mw * sizeof(double), M * sizeof(double), rows2d, hipMemcpyDeviceToHost));
+    else
+        HIP_TRY(hipMemcpy(buf, src, n * sizeof(double), hipMemcpyDeviceToHost));
     return EDRGP_OK;
 }
 

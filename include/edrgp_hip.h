@@ -91,7 +91,7 @@ int  edrgp_sync(edrgp_ctx* ctx);
  * factorisation of I + A succeeds without jitter and an error estimate stays below "f32_guard"
  * (EDRGP_GET_MODE reports 3 then; the bound is 1e-4..1e-3 accurate in that mode)).
  * A/B switches of individual optimisations, all on by default and result-neutral: "fuse_grad",
- * "rbf_epilogue", "syrk_xmap", "syrk_diag_opt", "chol_fused", "chol_rhs", "mfma_kbuild", "kbuild_tile" (64 / 128),
+ * "rbf_epilogue", "syrk_xmap", "syrk_diag_opt", "chol_fused", "chol_rhs", "pad_inducing", "mfma_kbuild", "kbuild_tile" (64 / 128),
  * "gemm_dephase", "tri_tile"; "side_cus" (CU-masked stream pair for bound-only evaluations, default 0 = off);
  * "trace" (host-side phase timing to stderr). */
 int  edrgp_set_option(edrgp_ctx* ctx, const char* key, double value);

@@ -183,6 +183,61 @@ def test_bound_only_rhs_row_equals_explicit_inverse(hip, N, M, D, mode):
     assert abs(row - ref) <= 1e-10 * abs(ref)
 
 
+@pytest.mark.parametrize("N,M,D,kinds,mode", [(1200, 300, 4, ["RBF"], 1), (1500, 449, 6, ["Matern52"], 0),
+                                              (1300, 257, 3, ["RBF", "Matern32"], 1), (1400, 390, 5, ["RBF"], 2)])
+def test_padded_inducing_set(hip, N, M, D, kinds, mode):
+    """M > 256 and not a multiple of 128: the evaluation works on the next multiple with decoupled phantom
+    inducing points.  Bound, gradients, posterior and the debug accessors must be those of the M-point problem
+    (oracle), and equal to the unpadded evaluation."""
+    X, y, Z = go.synthetic_problem(N, D, M, seed=N + M)
+    opts = [dict(variance=0.9 + 0.2 * i, lengthscale=(0.5 + 0.3 * i) * np.sqrt(D)) for i in range(len(kinds))]
+    kern = go.make_kernel(kinds, D, opts)
+    noise = 0.05
+    hip.set_data(X, y)
+    hip.set_inducing(Z)
+    set_kernel(hip, kern, noise)
+    hip.set_option("stats_mode", mode)
+    # both sides lose digits in proportion to cond(Kmm) (as in tools/fuzz.py)
+    amp = max(1.0, np.linalg.cond(kern.K(Z) + 1e-8 * np.eye(M)) / 1e6)
+    res = {}
+    try:
+        for pad in (0, 1):
+            hip.set_option("pad_inducing", pad)
+            lml_only = hip.sparse_lml()
+            out = hip.sparse_lml_grad()
+            hip.sparse_posterior()
+            mu, var = hip.predict(X[:40])
+            jac = hip.predict_grad(X[:40])
+            res[pad] = (lml_only, out, mu, var, jac, hip.get("LM", M * M).reshape(M, M), hip.get("WV", M),
+                        hip.get("BVEC", M))
+    finally:
+        hip.set_option("pad_inducing", 1)
+        hip.set_option("stats_mode", 0)
+    inf, kg, dn, dZ = oracle_sparse(kern, X, y, Z, noise)
+    ref = inf["log_marginal"][0, 0]
+    mu_ref, var_ref = go.raw_predict(kern, X[:40], Z, inf["woodbury_vector"], inf["woodbury_inv"])
+    jac_ref = go.predictive_gradients_mean(kern, X[:40], Z, inf["woodbury_vector"])[:, :, 0]
+    gscale = max(abs(dn), max(abs(g[0]) for g in kg), max(np.abs(g[1]).max() for g in kg))
+    for pad in (0, 1):
+        lml_only, out, mu, var, jac, Lm, wv, bvec = res[pad]
+        assert abs(lml_only - ref) <= 1e-9 * amp * abs(ref)
+        assert abs(out[0] - ref) <= 1e-9 * amp * abs(ref)
+        for p in range(len(kinds)):
+            assert abs(out[1][p] - kg[p][0]) <= 1e-6 * amp * gscale
+            assert abs(out[2][p].sum() - np.sum(kg[p][1])) <= 1e-6 * amp * gscale
+        assert abs(out[3] - dn) <= 1e-6 * amp * gscale
+        assert out[4].shape == (M, D)
+        assert np.abs(out[4] - dZ).max() <= 1e-5 * amp * max(np.abs(dZ).max(), 1e-3 * gscale)
+        assert np.abs(mu - mu_ref[:, 0]).max() <= 1e-7 * amp * np.abs(mu_ref).max()
+        assert np.abs(var - var_ref[:, 0]).max() <= 1e-6 * amp * max(1.0, np.abs(var_ref).max())
+        assert np.abs(jac - jac_ref).max() <= 1e-7 * amp * np.abs(jac_ref).max()
+        assert np.abs(wv - inf["woodbury_vector"][:, 0]).max() <= 1e-6 * amp * np.abs(inf["woodbury_vector"]).max()
+    # the real blocks of the padded evaluation are the unpadded ones
+    assert np.abs(res[1][5] - res[0][5]).max() <= 1e-12 * np.abs(res[0][5]).max()
+    assert np.abs(res[1][7] - res[0][7]).max() <= 1e-12 * np.abs(res[0][7]).max()
+    assert abs(res[1][0] - res[0][0]) <= 1e-11 * abs(res[0][0])
+
+
 def test_sparse_jitchol_retry_duplicate_inducing(hip):
     """Z with exact duplicates: Kmm + 1e-8 I is numerically singular for a wide RBF;
     the jitter ladder (GPy jitchol) must take over or succeed; result must be finite."""

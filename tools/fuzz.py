@@ -30,6 +30,7 @@ def run(h, seed=0, n_cases=60, modes=(0, 0, 1, 2), verbose=True):
       try:
           h.set_data(X, y); h.set_inducing(Z)
           h.set_kernel(kinds, [o["variance"] for o in opts], np.array([np.full(D, o["lengthscale"]) for o in opts]), noise)
+          lml_only = h.sparse_lml()          # bound-only evaluations take their own route through the second factorisation
           lml, dvar, dlen, dnoise, dZd = h.sparse_lml_grad()
           h.sparse_posterior()
           mu, var = h.predict(X[:50])
@@ -37,7 +38,7 @@ def run(h, seed=0, n_cases=60, modes=(0, 0, 1, 2), verbose=True):
           mu_ref, var_ref = go.raw_predict(kern, X[:50], Z, inf["woodbury_vector"], inf["woodbury_inv"])
           jac_ref = go.predictive_gradients_mean(kern, X[:50], Z, inf["woodbury_vector"])[:, :, 0]
           gscale = max(abs(dn), max(abs(g[0]) for g in kg), max(np.abs(g[1]).max() for g in kg))
-          errs = dict(lml=abs(lml - ref) / abs(ref),
+          errs = dict(lml=max(abs(lml - ref), abs(lml_only - ref)) / abs(ref),
                       dvar=max(abs(dvar[p] - kg[p][0]) for p in range(nparts)) / gscale,
                       dlen=max(abs(dlen[p].sum() - np.sum(kg[p][1])) for p in range(nparts)) / gscale,
                       dnoise=abs(dnoise - dn) / gscale,
