@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from edrgp_amd.backend import HipGP
 h = HipGP(0)
-for N in (2000, 8000, 16000, 32000):
+for N in [int(a) for a in sys.argv[1:]] or (2000, 8000, 16000, 32000):
     D = 8
     X, y, _ = bench.synthetic(N, D, 8, seed=3)
     h.set_data(X, y)
