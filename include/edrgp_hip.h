@@ -82,16 +82,19 @@ int  edrgp_ctx_destroy(edrgp_ctx* ctx);
 int  edrgp_sync(edrgp_ctx* ctx);
 /* tunables: "chunk_rows", "syrk_splits", "profile" (0/1), "stats_mode" (0 auto,
  * 1 Gram form Phi = K_mn K_nm, 2 stable form via K_nm Lm^-T), "pivot_ratio_max",
- * "overlap" (side-stream use: 0 none, 1 the Kmm gradient term beside the gradient contraction,
- * 2 also the Kmm Cholesky beside the row pass, 3 (default) = 2 for bound-only and 1 for
- * gradient evaluations), "precision" (64 default; 32 = BASELINE config 5: K_nm stored in fp32 and the
+ * "overlap" (side-stream use: 0 none, 1 the Kmm gradient term beside the gradient contraction and
+ * the K_nm build beside the Kmm factorisation, 2 the whole row pass beside the Kmm factorisation,
+ * 3 (default) = 1, and 2 only for bound-only evaluations whose row pass is chunked), "precision" (64 default; 32 = BASELINE config 5: K_nm stored in fp32 and the
  * gradient contraction T = (K_nm S2 + ..) .* h(r), T^T [X | X.^2] on the fp32 MFMA with fp64 slab sums,
  * for single-part kernels with D <= 64 while Kmm is conditioned for the Gram form; the bound itself stays
  * fp64.  "f32_phi" = 1 additionally tries the Gram matrix Phi in fp32 and keeps it only if the
  * factorisation of I + A succeeds without jitter and an error estimate stays below "f32_guard"
  * (EDRGP_GET_MODE reports 3 then; the bound is 1e-4..1e-3 accurate in that mode)).
  * A/B switches of individual optimisations, all on by default and result-neutral: "fuse_grad",
- * "rbf_epilogue", "syrk_xmap", "syrk_diag_opt", "chol_fused", "chol_rhs", "pad_inducing", "mfma_kbuild", "kbuild_tile" (64 / 128),
+ * "rbf_epilogue", "syrk_xmap", "syrk_diag_opt", "chol_fused",
+ * "chol_rhs" (bound-only: right-hand side carried through the second factorisation, no explicit inverse),
+ * "pad_inducing" (M > 256 not a multiple of 128: decoupled phantom inducing points up to the next multiple),
+ * "mfma_kbuild", "kbuild_tile" (64 / 128),
  * "gemm_dephase", "tri_tile"; "side_cus" (CU-masked stream pair for bound-only evaluations, default 0 = off);
  * "trace" (host-side phase timing to stderr). */
 int  edrgp_set_option(edrgp_ctx* ctx, const char* key, double value);
