@@ -206,6 +206,46 @@ __global__ void scale_norm_kernel(const double* __restrict__ X, int64_t rows, in
     xn[n] = s;
 }
 
+// Same result, coalesced: one wave per 64 consecutive rows (a contiguous run of 64 D doubles), scaled values
+// written straight back and parked in LDS (row stride D + 1: conflict-free), then lane r sums row r in the
+// same feature order as the kernel above.  D <= 64.  (The row-per-thread form reads with a stride of D doubles:
+// 363 us for 200 000 x 64, three times per C4 evaluation.)
+__global__ __launch_bounds__(64) void scale_norm_tile_kernel(const double* __restrict__ X, int64_t rows, int D,
+                                                             const double* __restrict__ invl, double* __restrict__ Xs,
+                                                             double* __restrict__ xn) {
+    extern __shared__ double tile[];                    // 64 x (D + 1)
+    const int lane = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    const int nr = (int)min((int64_t)64, rows - row0);
+    const int count = nr * D;
+    const double* src = X + (size_t)row0 * D;
+    double* dst = Xs + (size_t)row0 * D;
+    for (int e = lane; e < count; e += 64) {
+        const int r = e / D, q = e - r * D;
+        const double v = src[e] * invl[q];
+        dst[e] = v;
+        tile[r * (D + 1) + q] = v;
+    }
+    __syncthreads();
+    if (lane < nr) {
+        double s = 0.0;
+        for (int q = 0; q < D; ++q) {
+            const double v = tile[lane * (D + 1) + q];
+            s = fma(v, v, s);
+        }
+        xn[row0 + lane] = s;
+    }
+}
+
+static void launch_scale_norm(Ctx* c, const double* X, int64_t rows, int D, const double* invl, double* Xs, double* xn) {
+    if (D <= 64 && rows >= 4096)
+        hipLaunchKernelGGL(scale_norm_tile_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64),
+                           (size_t)64 * (D + 1) * sizeof(double), c->stream, X, rows, D, invl, Xs, xn);
+    else
+        hipLaunchKernelGGL(scale_norm_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, c->stream, X, rows, D, invl,
+                           Xs, xn);
+}
+
 // Single-part kernels: inner products of the scaled inputs on the matrix pipe (NT GEMM over
 // the feature dimension) + covariance epilogue.  |x|^2 + |z|^2 - 2 x.z is GPy's own formula.
 static int kernel_matrix_mfma(Ctx* c, const KSpec& ks, const double* X, int64_t rows, const double* X2, int M2,
@@ -214,15 +254,13 @@ static int kernel_matrix_mfma(Ctx* c, const KSpec& ks, const double* X, int64_t 
     const bool self = (X2 == X) && (rows == M2);
     TRY(c->ks_x.reserve((size_t)rows * D * sizeof(double)));
     TRY(c->ks_xn.reserve((size_t)rows * sizeof(double)));
-    hipLaunchKernelGGL(scale_norm_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, c->stream, X, rows, D,
-                       ks.invl, c->ks_x.d(), c->ks_xn.d());
+    launch_scale_norm(c, X, rows, D, ks.invl, c->ks_x.d(), c->ks_xn.d());
     const double* Zs = c->ks_x.d();
     const double* zn = c->ks_xn.d();
     if (!self) {
         TRY(c->ks_z.reserve((size_t)M2 * D * sizeof(double)));
         TRY(c->ks_zn.reserve((size_t)M2 * sizeof(double)));
-        hipLaunchKernelGGL(scale_norm_kernel, dim3((unsigned)((M2 + 255) / 256)), dim3(256), 0, c->stream, X2,
-                           (int64_t)M2, D, ks.invl, c->ks_z.d(), c->ks_zn.d());
+        launch_scale_norm(c, X2, (int64_t)M2, D, ks.invl, c->ks_z.d(), c->ks_zn.d());
         Zs = c->ks_z.d();
         zn = c->ks_zn.d();
     }
@@ -435,6 +473,30 @@ __global__ void scale_rows_neg_kernel(const double* __restrict__ Pt, const doubl
     if (i < Mp * Wd) out[i] = -wv[i / Wd] * Pt[i];
 }
 
+// out[m][q] = -wv[m] Z[m][q] (q < D), zero padding up to ldz
+__global__ void scale_z_neg_kernel(const double* __restrict__ Z, const double* __restrict__ wv, int Mp, int D, int ldz,
+                                   double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Mp * ldz) return;
+    const int m = i / ldz, q = i - m * ldz;
+    out[i] = (q < D) ? -wv[m] * Z[(size_t)m * D + q] : 0.0;
+}
+
+// RBF: jac[n][q] = invl[q]^2 (GZ[n][q] ... ) with G = -K diag(wv):  sum_m G = -(K wv)[n]
+//   jac[n][q] = invl[q]^2 * (-x[n][q] * kwv[n] - GZ[n][q]),  GZ = K (-diag(wv) Z)   (rows x ldz)
+__global__ void jac_finish_rbf_kernel(const double* __restrict__ Xs, const double* __restrict__ GZ,
+                                      const double* __restrict__ kwv, int64_t rows, int D, int ldz,
+                                      const double* __restrict__ invl, double* __restrict__ jac) {
+    const int64_t total = rows * D;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t n = i / D;
+        const int q = (int)(i - n * D);
+        const double il = invl[q];
+        jac[i] = il * il * (-(Xs[i] * kwv[n]) - GZ[n * ldz + q]);
+    }
+}
+
 int predict_chunk(Ctx* c, const KSpec& ks, const double* Xs, int64_t rows, const double* P, const double* Pt,
                   int Mp, const double* wv, const double* winv, double kdiag, double* Kbuf, double* Gbuf,
                   double* GT, double* mean, double* var, double* jac, bool k_ready) {
@@ -457,10 +519,27 @@ int predict_chunk(Ctx* c, const KSpec& ks, const double* Xs, int64_t rows, const
         const int Wd = 2 * D + 1;
         for (int p = 0; p < ks.nparts; ++p) {
             if (rbf1) {
-                TRY(c->ptw.reserve((size_t)Mp * Wd * sizeof(double)));
-                hipLaunchKernelGGL(scale_rows_neg_kernel, dim3((Mp * Wd + 255) / 256), dim3(256), 0, c->stream, Pt, wv, Mp,
-                                   Wd, c->ptw.d());
-                TRY(gemm(c, false, false, (int)rows, Wd, Mp, 1.0, Kbuf, Mp, c->ptw.d(), Wd, 0.0, GT, Wd));
+                // The Jacobian needs sum_m G[n][m] Z[m][:] and sum_m G[n][m] only (the Z.^2 columns of Pt serve
+                // the length-scale gradient, not this), and with G = -K diag(wv) the second is minus the
+                // posterior mean: one rows x D x Mp product on an even leading dimension instead of
+                // rows x (2D+1) x Mp on an odd one (a second, one-column tile and the guarded loaders: C4,
+                // d = 64: 2.3 -> 0.5 ms).
+                const int ldz = D + (D & 1);
+                TRY(c->ptw.reserve((size_t)Mp * ldz * sizeof(double)));
+                hipLaunchKernelGGL(scale_z_neg_kernel, dim3((Mp * ldz + 255) / 256), dim3(256), 0, c->stream, P, wv, Mp, D,
+                                   ldz, c->ptw.d());
+                TRY(gemm(c, false, false, (int)rows, ldz, Mp, 1.0, Kbuf, Mp, c->ptw.d(), ldz, 0.0, GT, ldz));
+                const double* kwv = mean;
+                if (kwv == nullptr) {
+                    double* tmp = GT + (size_t)rows * ldz;          // GT holds rows x (2D+1) >= rows x (ldz + 1)
+                    TRY(gemv_n(c, (int)rows, Mp, 1.0, Kbuf, Mp, wv, tmp));
+                    kwv = tmp;
+                }
+                const int64_t total = rows * D;
+                const int nb = (int)std::min<int64_t>(4096, (total + 255) / 256);
+                hipLaunchKernelGGL(jac_finish_rbf_kernel, dim3(std::max(nb, 1)), dim3(256), 0, c->stream, Xs, GT, kwv, rows,
+                                   D, ldz, ks.invl, jac);
+                continue;
             } else {
                 TRY(hmatrix(c, ks, p, Xs, rows, P, Mp, wv, Gbuf, Mp));
                 TRY(gemm(c, false, false, (int)rows, Wd, Mp, 1.0, Gbuf, Mp, Pt, Wd, 0.0, GT, Wd));
