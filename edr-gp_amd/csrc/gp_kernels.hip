@@ -206,21 +206,21 @@ __global__ void scale_norm_kernel(const double* __restrict__ X, int64_t rows, in
     xn[n] = s;
 }
 
-// Same result, coalesced: one wave per 64 consecutive rows (a contiguous run of 64 D doubles), scaled values
+// Same result, coalesced: one workgroup per 64 consecutive rows (a contiguous run of 64 D doubles), scaled values
 // written straight back and parked in LDS (row stride D + 1: conflict-free), then lane r sums row r in the
 // same feature order as the kernel above.  D <= 64.  (The row-per-thread form reads with a stride of D doubles:
 // 363 us for 200 000 x 64, three times per C4 evaluation.)
-__global__ __launch_bounds__(64) void scale_norm_tile_kernel(const double* __restrict__ X, int64_t rows, int D,
+__global__ __launch_bounds__(256) void scale_norm_tile_kernel(const double* __restrict__ X, int64_t rows, int D,
                                                              const double* __restrict__ invl, double* __restrict__ Xs,
                                                              double* __restrict__ xn) {
     extern __shared__ double tile[];                    // 64 x (D + 1)
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x;                       // 256 threads move the tile, the first 64 sum its rows
     const int64_t row0 = (int64_t)blockIdx.x * 64;
     const int nr = (int)min((int64_t)64, rows - row0);
     const int count = nr * D;
     const double* src = X + (size_t)row0 * D;
     double* dst = Xs + (size_t)row0 * D;
-    for (int e = lane; e < count; e += 64) {
+    for (int e = lane; e < count; e += 256) {
         const int r = e / D, q = e - r * D;
         const double v = src[e] * invl[q];
         dst[e] = v;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64) void scale_norm_tile_kernel(const double* __res
 
 static void launch_scale_norm(Ctx* c, const double* X, int64_t rows, int D, const double* invl, double* Xs, double* xn) {
     if (D <= 64 && rows >= 4096)
-        hipLaunchKernelGGL(scale_norm_tile_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64),
+        hipLaunchKernelGGL(scale_norm_tile_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256),
                            (size_t)64 * (D + 1) * sizeof(double), c->stream, X, rows, D, invl, Xs, xn);
     else
         hipLaunchKernelGGL(scale_norm_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, c->stream, X, rows, D, invl,
