@@ -32,7 +32,9 @@ __global__ __launch_bounds__(256) void mfma_f64_rate_kernel(int iters, double* s
 // 64 MFMAs (= one k-tile): 1 = LDS fragment reads (8 per 16 MFMAs), 2 = workgroup barrier,
 // 4 = 8 ds_write_b128 (staging stores), 8 = 8 streaming global_load_dwordx4.
 // AG = 1: accumulators in AGPRs; ONE = 1: a single A/B pair.
-template <int F, int AG, int ONE>
+// ORD: order of the 16 MFMAs of a k-step over the accumulator grid: 0 x-major, 1 y-major, 2 snake, 3 rotated
+// (consecutive instructions share neither operand)
+template <int F, int AG, int ONE, int ORD = 0>
 __global__ __launch_bounds__(256, 2) void mfma_pattern_kernel(int iters, double* sink, const double* __restrict__ gsrc,
                                                              long long gstride) {
     __shared__ __attribute__((aligned(16))) double lds[2][16][144];
@@ -67,13 +69,14 @@ __global__ __launch_bounds__(256, 2) void mfma_pattern_kernel(int iters, double*
                 for (int x = 0; x < 4; ++x) { a[x] = lds[buf][kk * 4 + lq][x * 16 + lr]; b[x] = lds[buf][kk * 4 + lq][64 + x * 16 + lr]; }
             }
 #pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int y = 0; y < 4; ++y) {
-                    if (AG) MFMA_A(acc[x][y], a[x], b[y]);
-                    else if (ONE) MFMA_V(acc[x][y], a[0], b[0]);
-                    else MFMA_V(acc[x][y], a[x], b[y]);
-                }
+            for (int i = 0; i < 16; ++i) {
+                const int x = (ORD == 1) ? (i & 3) : (ORD == 3) ? (i & 3) : (i >> 2);
+                const int y = (ORD == 1) ? (i >> 2) : (ORD == 2) ? (((i >> 2) & 1) ? 3 - (i & 3) : (i & 3))
+                            : (ORD == 3) ? (((i >> 2) + (i & 3)) & 3) : (i & 3);
+                if (AG) MFMA_A(acc[x][y], a[x], b[y]);
+                else if (ONE) MFMA_V(acc[x][y], a[0], b[0]);
+                else MFMA_V(acc[x][y], a[x], b[y]);
+            }
         }
         if (F & 4) {
 #pragma unroll
@@ -163,14 +166,14 @@ __global__ __launch_bounds__(256, 1) void mfma_bigtile_kernel(int iters, double*
     if (s[0] + s[1] + s[2] + s[3] + st[3].x == -1.0) sink[0] = s[0];
 }
 
-template <int F, int AG, int ONE>
+template <int F, int AG, int ONE, int ORD = 0>
 static int run_pattern(Ctx* c, int blocks, int iters, const double* gs, long long gstride, double* tf) {
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     for (int rep = 0; rep < 2; ++rep) {
         if (rep == 1) HIP_TRY(hipEventRecord(e0, c->stream));
-        hipLaunchKernelGGL((mfma_pattern_kernel<F, AG, ONE>), dim3(blocks), dim3(256), 0, c->stream, iters, c->red.d(),
+        hipLaunchKernelGGL((mfma_pattern_kernel<F, AG, ONE, ORD>), dim3(blocks), dim3(256), 0, c->stream, iters, c->red.d(),
                            gs, gstride);
     }
     HIP_TRY(hipEventRecord(e1, c->stream));
@@ -218,6 +221,27 @@ int calib_mfma_patterns(Ctx* c, double* t) {
         (void)hipEventDestroy(e1);
         t[8 + pf] = (double)c->num_cu * 4.0 * it2 * 128.0 * 2048.0 / (ms * 1e-3) * 1e-12;
     }
+    g.release();
+    return EDRGP_OK;
+}
+
+// issue order of the 16 MFMAs of a k-step: registers only and the full loop skeleton, per order
+int calib_mfma_orders(Ctx* c, double* t) {
+    TRY(c->red.reserve(64));
+    const int iters = 600, blocks = c->num_cu * 2;
+    const long long gstride = (long long)(iters + 2) * 32768;
+    DBuf g;
+    TRY(g.reserve((size_t)blocks * gstride));
+    HIP_TRY(hipMemsetAsync(g.p, 0, g.bytes, c->stream));
+    const double* gs = g.d();
+    TRY((run_pattern<0, 0, 0, 0>(c, blocks, iters, gs, gstride, &t[0])));
+    TRY((run_pattern<0, 0, 0, 1>(c, blocks, iters, gs, gstride, &t[1])));
+    TRY((run_pattern<0, 0, 0, 2>(c, blocks, iters, gs, gstride, &t[2])));
+    TRY((run_pattern<0, 0, 0, 3>(c, blocks, iters, gs, gstride, &t[3])));
+    TRY((run_pattern<15, 0, 0, 0>(c, blocks, iters, gs, gstride, &t[4])));
+    TRY((run_pattern<15, 0, 0, 1>(c, blocks, iters, gs, gstride, &t[5])));
+    TRY((run_pattern<15, 0, 0, 2>(c, blocks, iters, gs, gstride, &t[6])));
+    TRY((run_pattern<15, 0, 0, 3>(c, blocks, iters, gs, gstride, &t[7])));
     g.release();
     return EDRGP_OK;
 }
