@@ -242,6 +242,8 @@ int calib_mfma_orders(Ctx* c, double* t) {
     TRY((run_pattern<15, 0, 0, 1>(c, blocks, iters, gs, gstride, &t[5])));
     TRY((run_pattern<15, 0, 0, 2>(c, blocks, iters, gs, gstride, &t[6])));
     TRY((run_pattern<15, 0, 0, 3>(c, blocks, iters, gs, gstride, &t[7])));
+    TRY((run_pattern<0, 0, 0, 0>(c, c->num_cu, iters, gs, gstride, &t[8])));       // one workgroup per CU: a lone wave per SIMD
+    TRY((run_pattern<0, 0, 1, 0>(c, c->num_cu, iters, gs, gstride, &t[9])));
     g.release();
     return EDRGP_OK;
 }
