@@ -1642,13 +1642,13 @@ int edrgp_calib(edrgp_ctx* ctx, double* mfma_f64_tflops, double* hbm_copy_gbps) 
                 t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9]);
     }
     if (getenv("EDRGP_CALIB_ORDERS")) {
-        double t[10] = {0};
+        double t[12] = {0};
         for (int rep = 0; rep < 2; ++rep) {
             TRY(calib_mfma_orders(c, t));
             fprintf(stderr, "[calib] fp64 MFMA TFLOP/s by issue order of a k-step's 16 MFMAs (x-major | y-major | snake | rotated): "
                             "registers only %.1f %.1f %.1f %.1f ; full loop skeleton %.1f %.1f %.1f %.1f ; one wave per SIMD, registers only: "
-                            "4x4 grid %.1f, one A/B pair %.1f\n",
-                    t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9]);
+                            "4x4 grid %.1f, one A/B pair %.1f ; loop skeleton with fragment prefetch: staging after k-step 1 %.1f, after k-step 3 %.1f\n",
+                    t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10], t[11]);
         }
     }
     if (mfma_f64_tflops) TRY(calib_mfma_f64(c, mfma_f64_tflops));

@@ -34,6 +34,67 @@ __global__ __launch_bounds__(256) void mfma_f64_rate_kernel(int iters, double* s
 // AG = 1: accumulators in AGPRs; ONE = 1: a single A/B pair.
 // ORD: order of the 16 MFMAs of a k-step over the accumulator grid: 0 x-major, 1 y-major, 2 snake, 3 rotated
 // (consecutive instructions share neither operand)
+// The loop skeleton (F = 15) with the fragments of k-step s+1 read during the MFMAs of step s (register
+// double-buffered fragments, +16 VGPRs); WR = k-step after which the staging stores are issued.
+template <int WR>
+__global__ __launch_bounds__(256, 2) void mfma_prefetch_kernel(int iters, double* sink, const double* __restrict__ gsrc,
+                                                              long long gstride) {
+    __shared__ __attribute__((aligned(16))) double lds[2][16][144];
+    const int lane = threadIdx.x & 63;
+    const int lr = lane & 15, lq = lane >> 4;
+    for (int i = threadIdx.x; i < 2 * 16 * 144; i += 256) (&lds[0][0][0])[i] = 1.0 + 1e-6 * i;
+    __syncthreads();
+    double a[2][4], b[2][4];
+    d4 acc[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] = d4{0, 0, 0, 0};
+    const char* gbase = reinterpret_cast<const char*>(gsrc) + (long long)blockIdx.x * gstride;
+    const unsigned goff = threadIdx.x * 16;
+    double2 st[8];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) st[v] = double2{1.0, 2.0};
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { a[0][x] = lds[0][lq][x * 16 + lr]; b[0][x] = lds[0][lq][64 + x * 16 + lr]; }
+    for (int i = 0; i < iters; ++i) {
+        const int buf = i & 1;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) st[v] = *reinterpret_cast<const double2*>(gbase + goff + v * 4096);
+        gbase += 32768;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk < 3) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    a[nxt][x] = lds[buf][(kk + 1) * 4 + lq][x * 16 + lr];
+                    b[nxt][x] = lds[buf][(kk + 1) * 4 + lq][64 + x * 16 + lr];
+                }
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) MFMA_V(acc[x][y], a[cur][x], b[cur][y]);
+            if (kk == WR) {
+#pragma unroll
+                for (int v = 0; v < 8; ++v)
+                    *reinterpret_cast<double2*>(&lds[buf ^ 1][(v * 2 + (threadIdx.x >> 7)) & 15][(threadIdx.x & 63) * 2]) = st[v];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { a[0][x] = lds[buf ^ 1][lq][x * 16 + lr]; b[0][x] = lds[buf ^ 1][lq][64 + x * 16 + lr]; }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15");
+    d4 s = {0, 0, 0, 0};
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) s += acc[x][y];
+    if (s[0] + s[1] + s[2] + s[3] + st[3].x == -1.0) sink[0] = s[0];
+}
+
 template <int F, int AG, int ONE, int ORD = 0>
 __global__ __launch_bounds__(256, 2) void mfma_pattern_kernel(int iters, double* sink, const double* __restrict__ gsrc,
                                                              long long gstride) {
@@ -242,6 +303,23 @@ int calib_mfma_orders(Ctx* c, double* t) {
     TRY((run_pattern<15, 0, 0, 1>(c, blocks, iters, gs, gstride, &t[5])));
     TRY((run_pattern<15, 0, 0, 2>(c, blocks, iters, gs, gstride, &t[6])));
     TRY((run_pattern<15, 0, 0, 3>(c, blocks, iters, gs, gstride, &t[7])));
+    for (int wr = 0; wr < 2; ++wr) {                 // fragment prefetch; staging stores after k-step 1 or 3
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        for (int rep = 0; rep < 2; ++rep) {
+            if (rep == 1) HIP_TRY(hipEventRecord(e0, c->stream));
+            if (wr == 0) hipLaunchKernelGGL((mfma_prefetch_kernel<1>), dim3(blocks), dim3(256), 0, c->stream, iters, c->red.d(), gs, gstride);
+            else hipLaunchKernelGGL((mfma_prefetch_kernel<3>), dim3(blocks), dim3(256), 0, c->stream, iters, c->red.d(), gs, gstride);
+        }
+        HIP_TRY(hipEventRecord(e1, c->stream));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        t[10 + wr] = (double)blocks * 4.0 * iters * 64.0 * 2048.0 / (ms * 1e-3) * 1e-12;
+    }
     TRY((run_pattern<0, 0, 0, 0>(c, c->num_cu, iters, gs, gstride, &t[8])));       // one workgroup per CU: a lone wave per SIMD
     TRY((run_pattern<0, 0, 1, 0>(c, c->num_cu, iters, gs, gstride, &t[9])));
     g.release();

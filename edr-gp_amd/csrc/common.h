@@ -197,7 +197,7 @@ int grad_contract32(Ctx* c, const KSpec& ks, const float* K32, int64_t rows, int
                     const double* wv, double ycoef, float* T32, double* dvar_accum, double* cs);
 int calib_mfma_f64(Ctx* c, double* tflops);
 int calib_mfma_patterns(Ctx* c, double* tflops4);
-int calib_mfma_orders(Ctx* c, double* tflops10);
+int calib_mfma_orders(Ctx* c, double* tflops12);
 int calib_hbm_copy(Ctx* c, double* gbps);
 int mfma_layout_probe(Ctx* c, const double* A, const double* B, double* C);  // device ptrs
 
