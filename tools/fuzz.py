@@ -15,6 +15,9 @@ def run(h, seed=0, n_cases=60, modes=(0, 0, 1, 2), verbose=True):
       D = int(rng.integers(1, 10)) if case % 5 else int(rng.integers(33, 45))
       M = int(rng.integers(1, 200))
       N = int(rng.integers(max(M, 2), 900))
+      if case % 7 == 3:        # inducing sets beyond 256: phantom padding to a multiple of 128, the (M + 1)-row bound-only path
+          M = int(rng.integers(257, 520))
+          N = int(rng.integers(M, 1600))
       nparts = 1 if rng.random() < 0.7 else 2
       kinds = [kinds_all[int(rng.integers(0, 3))] for _ in range(nparts)]
       opts = [dict(variance=float(rng.uniform(0.3, 2.0)), lengthscale=float(rng.uniform(0.8, 3.0) * np.sqrt(D))) for _ in range(nparts)]
@@ -38,7 +41,9 @@ def run(h, seed=0, n_cases=60, modes=(0, 0, 1, 2), verbose=True):
           mu_ref, var_ref = go.raw_predict(kern, X[:50], Z, inf["woodbury_vector"], inf["woodbury_inv"])
           jac_ref = go.predictive_gradients_mean(kern, X[:50], Z, inf["woodbury_vector"])[:, :, 0]
           gscale = max(abs(dn), max(abs(g[0]) for g in kg), max(np.abs(g[1]).max() for g in kg))
-          errs = dict(lml=max(abs(lml - ref), abs(lml_only - ref)) / abs(ref),
+          # the bound is a sum of N terms of order one that can cancel to a small number: its error is measured
+          # against max(|bound|, N)
+          errs = dict(lml=max(abs(lml - ref), abs(lml_only - ref)) / max(abs(ref), float(N)),
                       dvar=max(abs(dvar[p] - kg[p][0]) for p in range(nparts)) / gscale,
                       dlen=max(abs(dlen[p].sum() - np.sum(kg[p][1])) for p in range(nparts)) / gscale,
                       dnoise=abs(dnoise - dn) / gscale,

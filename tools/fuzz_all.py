@@ -1,0 +1,11 @@
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import fuzz
+from edrgp_amd.backend import HipGP
+h = HipGP(0)
+tot = []
+for seed in (0, 1, 2, 3, 4, 5):
+    bad = fuzz.run(h, seed=seed, n_cases=70, modes=(0, 0, 2), verbose=True)
+    print("seed", seed, "failing", bad, flush=True)
+    tot += bad
+print("TOTAL failing:", len(tot))
