@@ -270,7 +270,7 @@ struct Ctx {
     int syrk_splits = 0;              // 0 = auto
     bool profile = false;
     int stats_mode = 0;               // 0 auto, 1 gram (Phi = K^T K), 2 stable (K Li^T first)
-    double pivot_ratio_max = 300.0;   // auto: stable when (max/min diag Lm)^2 exceeds this (configs: C2 248, Cm 61, C3 11, C5 27)
+    double pivot_ratio_max = 120.0;   // auto: stable when (max/min diag Lm)^2 exceeds this (configs: C2 248 -> stable; Cm 61, C3 11, C5 27 -> Gram)
     int last_mode = 0;
     double last_pivot_ratio2 = 0.0;
 

@@ -106,6 +106,40 @@ def test_full_size_properties(hip, name, N, M, D, kind):
         hip.set_option("chunk_rows", 131072)
 
 
+@pytest.mark.parametrize("name,N,M,D,kind", CONFIGS[:3], ids=[c[0] for c in CONFIGS[:3]])
+def test_full_size_gram_form_matches_stable_form(hip, name, N, M, D, kind):
+    """What the automatic mode runs at the BASELINE sizes -- the Gram form (one pass over the rows) at Cm and on
+    the C3 shard, the stable form at C2, whose Kmm is worse conditioned -- against the stable form, which applies
+    Lm^-1 to K_nm before the contraction as GPy does: bound within 1e-10, posterior mean within 1e-8 (SURVEY 8d's
+    gate; north_star asks for the mean within 1e-8), gradients within 1e-6."""
+    X, y, Z = synthetic(N, D, M, seed=7)
+    ls = np.full((1, D), np.sqrt(D))
+    hip.set_data(X, y)
+    hip.set_inducing(Z)
+    hip.set_kernel([kind], [1.0], ls, 0.01)
+    out = {}
+    try:
+        for mode in (0, 2):
+            hip.set_option("stats_mode", mode)
+            grads = hip.sparse_lml_grad()
+            bound_only = hip.sparse_lml()
+            hip.sparse_posterior()
+            mean, jac = hip.predict_train()
+            out[mode] = (grads, bound_only, mean, jac)
+            ran = int(hip.get("MODE", (1,))[0])
+            assert ran == (2 if (mode == 2 or name == "C2") else 1)
+    finally:
+        hip.set_option("stats_mode", 0)
+    (g, gb, gm, gj), (s, sb, sm, sj) = out[0], out[2]
+    rel = lambda a, b: float(np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(np.asarray(b)).max())
+    assert abs(g[0] - s[0]) <= 1e-10 * abs(s[0])
+    assert abs(gb - sb) <= 1e-10 * abs(sb)
+    assert rel(g[1], s[1]) <= 1e-6 and rel(g[2], s[2]) <= 1e-6 and abs(g[3] - s[3]) <= 1e-6 * abs(s[3])
+    assert rel(g[4], s[4]) <= 1e-6
+    assert rel(gm, sm) <= 1e-8
+    assert rel(gj, sj) <= 5e-8
+
+
 def test_c5_full_size_fp32_row_pass(hip):
     """BASELINE config 5 (N=2M, M=4096, D=64, RBF, fp32 path) at full size, checked against the
     fp64 device path on the same inputs (itself pinned to the oracle at small sizes and by the
