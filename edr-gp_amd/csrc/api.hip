@@ -424,9 +424,23 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
             const double* S = c->Knm.d();
             if (stable) {
                 ProfScope ps(c, EDRGP_PROF_GRADGEMM);
-                TRY(gemm(c, false, true, (int)rows, M, M, 1.0, c->Knm.d(), M, Li, M, 0.0, c->W.d(), M,
-                         kopt(K_LE_COL, 0, 2)));
-                TRY(gemv_t(c, (int)rows, M, 1.0, c->W.d(), M, c->y.d() + r0, btarget));
+                // W = K_nm Li^T with b = W^T y out of the same launch's epilogue (per-row-tile partials, fixed order)
+                const int tiles_m = (int)((rows + 127) / 128);
+                TRY(c->bpart.reserve((size_t)tiles_m * M * sizeof(double)));
+                FuseK fk{};
+                fk.y = c->y.d() + r0;
+                fk.bpart = c->bpart.d();
+                GemmOpts ow = kopt(K_LE_COL, 0, 4);
+                ow.force_tile = 128;
+                ow.fusek = &fk;
+                if (rows >= 128 && M >= 128) {
+                    TRY(gemm(c, false, true, (int)rows, M, M, 1.0, c->Knm.d(), M, Li, M, 0.0, c->W.d(), M, ow));
+                    TRY(col_reduce(c, c->bpart.d(), tiles_m, M, btarget));
+                } else {
+                    TRY(gemm(c, false, true, (int)rows, M, M, 1.0, c->Knm.d(), M, Li, M, 0.0, c->W.d(), M,
+                             kopt(K_LE_COL, 0, 2)));
+                    TRY(gemv_t(c, (int)rows, M, 1.0, c->W.d(), M, c->y.d() + r0, btarget));
+                }
                 S = c->W.d();
             }
             if (ch > 0) TRY(vec_axpy(c, M, 1.0, v_tmp, bvec));

@@ -791,6 +791,45 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         return;
     }
 
+    // ---- TAG 4: plain store + column sums weighted by a row vector (W = K_nm Li^T and W^T y in one pass:
+    //      the stable form's b, without reading W back)
+    if (TAG == 4) {
+        const FuseK& f = g.fusek;
+        double bsum[TN];
+#pragma unroll
+        for (int y = 0; y < TN; ++y) bsum[y] = 0.0;
+#pragma unroll
+        for (int x = 0; x < TM; ++x)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * WM + x * 16 + lq + 4 * r;
+                const bool rok = row < Meff;
+                const double yr = rok ? f.y[row] : 0.0;
+#pragma unroll
+                for (int y = 0; y < TN; ++y) {
+                    const int col = n0 + wn * WN + y * 16 + lr;
+                    if (rok && col < g.N) {
+                        const double v = acc[x][y][r];
+                        C[(size_t)row * g.ldc + col] = v;
+                        bsum[y] = fma(v, yr, bsum[y]);
+                    }
+                }
+            }
+        // 8 partials per column (2 row-waves x 4 lane rows), summed in a fixed order
+        __syncthreads();
+        double* red = &As[0][0];
+#pragma unroll
+        for (int y = 0; y < TN; ++y) red[((wm * 4 + lq) * BN) + wn * WN + y * 16 + lr] = bsum[y];
+        __syncthreads();
+        for (int j = tid; j < BN; j += 256) {
+            double sum = 0.0;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) sum += red[p * BN + j];
+            if (n0 + j < g.N) f.bpart[(size_t)ti * g.N + n0 + j] = sum;
+        }
+        return;
+    }
+
     // ---- epilogue
     const double alpha = g.alpha, beta = g.beta;
 #pragma unroll
@@ -837,6 +876,7 @@ static void launch_variant(bool akm, bool bkm, int tag, dim3 grid, hipStream_t s
     else if (tag == 1 && akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, true, 1>), grid, dim3(256), 0, s, g);
     else if (tag == 2 && !akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, true, 2>), grid, dim3(256), 0, s, g);
     else if (tag == 3 && !akm && !bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, false, 3>), grid, dim3(256), 0, s, g);
+    else if (tag == 4 && !akm && !bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, false, 4>), grid, dim3(256), 0, s, g);
     else if (akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, true, 0>), grid, dim3(256), 0, s, g);
     else if (akm && !bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, false, 0>), grid, dim3(256), 0, s, g);
     else if (!akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, true, 0>), grid, dim3(256), 0, s, g);
@@ -872,9 +912,13 @@ static int gemm_impl(Ctx* c, bool transA, bool transB, int M, int N, int K, doub
     g.dephase = c->gemm_dephase;
     g.stamps = nullptr;
     g.fuse_on = 0;
-    if (o.tag == 3) {
+    if (o.tag == 3 || o.tag == 4) {
         if (o.fusek == nullptr || splits != 1 || o.batch != 1 || o.tri) {
-            set_error("kernel-matrix epilogue needs an unsplit, unbatched, full-grid product");
+            set_error("kernel-matrix / column-sum epilogue needs an unsplit, unbatched, full-grid product");
+            return EDRGP_ERR_INVALID;
+        }
+        if (o.tag == 4 && (transA || !transB || o.fusek->y == nullptr || o.fusek->bpart == nullptr || alpha != 1.0 || beta != 0.0)) {
+            set_error("column-sum epilogue: NT product, alpha = 1, beta = 0, y and bpart required");
             return EDRGP_ERR_INVALID;
         }
         g.fusek = *o.fusek;
