@@ -1132,6 +1132,7 @@ int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
     else if (!std::strcmp(key, "chol_fused")) c->chol_fused = (value != 0.0);
     else if (!std::strcmp(key, "chol_rhs")) c->chol_rhs = (value != 0.0);
     else if (!std::strcmp(key, "pad_inducing")) c->pad_inducing = (value != 0.0);
+    else if (!std::strcmp(key, "gemm_pair")) c->gemm_pair = (value != 0.0);
     else if (!std::strcmp(key, "prebuild")) c->prebuild = (value != 0.0);
     else if (!std::strcmp(key, "syrk_xmap")) c->syrk_xmap = (value != 0.0);
     else if (!std::strcmp(key, "syrk_diag_opt")) c->syrk_diag_opt = (value != 0.0);

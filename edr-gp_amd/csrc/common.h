@@ -224,6 +224,7 @@ struct Ctx {
     bool syrk_diag_opt = true;        // Phi: diagonal tiles compute their 36 lower 16x16 blocks only
     bool syrk_xmap = true;            // Phi: split-major workgroup -> XCD map (la_gemm.hip)
     bool prebuild = true;             // gradient evaluations: K_nm build on the main stream beside phase 1 on the side stream
+    bool gemm_pair = true;            // stable form's K_nm Li^T: column tiles paired (long, short) per workgroup
     bool pad_inducing = true;         // sparse evaluations: embed M inducing points in the next multiple of 128 (api.hip)
     int M_work = 0;                   // working size of the last sparse evaluation (>= M)
     bool chol_rhs = true;             // bound-only evaluations: L_B^-1 (beta v) as an extra row of the factorisation, no explicit L_B^-1

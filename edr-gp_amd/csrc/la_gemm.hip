@@ -39,6 +39,7 @@ struct GemmArgs {
     int splits;
     long long slabStride;
     int tiles_m, tiles_n, tri;
+    int pair;               // TAG 4 with K_LE_COL: a workgroup owns column tiles (T-1-p, p): constant k-range per workgroup
     int vecA, vecB;
     unsigned long long* stamps;   // TAG 9 only
     FuseT fuse;                   // TAG 2 only, used when fuse_on
@@ -431,9 +432,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         while ((long long)(ti + 1) * (ti + 2) / 2 <= t) ++ti;
         while ((long long)ti * (ti + 1) / 2 > t) --ti;
         tj = t - (int)((long long)ti * (ti + 1) / 2);
+    } else if (TAG == 4 && g.pair) {
+        const int half = (g.tiles_n + 1) / 2;
+        ti = t / half;
+        tj = g.tiles_n - 1 - (t - ti * half);          // the long column tile first, its short partner second
     } else {
         ti = t / g.tiles_n;
         tj = t - ti * g.tiles_n;
+    }
+    // Zero-skipping over a lower-triangular right operand gives column tile j a k-range of (j + 1) tiles: paired
+    // (T-1-p, p), every workgroup runs T + 1 of them and half as many workgroups pay prologue and drain.
+    const int tj_second = g.tiles_n - 1 - tj;
+    const int npass = (TAG == 4 && g.pair && tj_second != tj) ? 2 : 1;
+#pragma clang loop unroll(disable)
+    for (int pass = 0; pass < npass; ++pass) {
+    if (pass == 1) {
+        tj = tj_second;
+        __syncthreads();                               // the first tile's epilogue is done with the LDS
     }
 
     const int z = blockIdx.z;
@@ -441,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     if (g.limM_stride) Meff = min(Meff, g.limM_base - z * g.limM_stride);
     if (g.limK_stride) Keff = min(Keff, g.limK_base - z * g.limK_stride);
     const int m0 = ti * BM, n0 = tj * BN;
-    if (Meff <= 0 || m0 >= Meff || n0 >= g.N) return;
+    if (Meff <= 0 || m0 >= Meff || n0 >= g.N) continue;
 
     const double* A = g.A + (long long)z * g.strideA;
     const double* B = g.B + (long long)z * g.strideB;
@@ -479,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                 else if (wave_u == 2) diag_tile_run<2, LA>(g, A, C, As, tid, lr, lq, m0, kt0, kt1);
                 else diag_tile_run<3, LA>(g, A, C, As, tid, lr, lq, m0, kt0, kt1);
             }
-            return;
+            continue;
         }
     }
 
@@ -636,7 +651,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                 if (n0 + j < g.N) f.bpart[(size_t)ti * g.N + n0 + j] = sum;
             }
         }
-        return;
+        continue;
     }
 
     // ---- fused gradient epilogue (TAG 2): T = (acc + ycoef y wv^T) .* h(r), sum Q .* k / var
@@ -718,7 +733,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                 }
             fused_epilogue_reduce<BN, WN, TN>(f, csum, dv, &Bs[0][0], tid, wm, wn, lr, lq, n0, g.N, ti,
                                               (size_t)blockIdx.z * gridDim.x + blockIdx.x);
-            return;
+            continue;
         }
         // one feature chunk (the host fuses only when D <= DC): stage, then one row block
         // of accumulators at a time to keep the register footprint at acc + 16 doubles
@@ -788,7 +803,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         }
         fused_epilogue_reduce<BN, WN, TN>(f, csum, dv, &Bs[0][0], tid, wm, wn, lr, lq, n0, g.N, ti,
                                           (size_t)blockIdx.z * gridDim.x + blockIdx.x);
-        return;
+        continue;
     }
 
     // ---- TAG 4: plain store + column sums weighted by a row vector (W = K_nm Li^T and W^T y in one pass:
@@ -827,7 +842,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
             for (int p = 0; p < 8; ++p) sum += red[p * BN + j];
             if (n0 + j < g.N) f.bpart[(size_t)ti * g.N + n0 + j] = sum;
         }
-        return;
+        continue;
     }
 
     // ---- epilogue
@@ -849,6 +864,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
             }
         }
     }
+    }   // pass
 }
 
 // C[i][j] = alpha * sum_s slab[s][i][j] + beta * C[i][j]; mirror: computed for
@@ -949,6 +965,8 @@ static int gemm_impl(Ctx* c, bool transA, bool transB, int M, int N, int K, doub
                  (M % 128 == 0) && (K % BK == 0) && g.vecA && ((long long)BK * lda < (1LL << 28)) && A == B && lda == ldb &&
                  o.batch == 1;
     long long nt = o.tri ? (long long)g.tiles_m * (g.tiles_m + 1) / 2 : (long long)g.tiles_m * g.tiles_n;
+    g.pair = (o.tag == 4 && (o.kmode == K_LE_COL) && g.tiles_n >= 2 && c->gemm_pair) ? 1 : 0;
+    if (g.pair) nt = (long long)g.tiles_m * ((g.tiles_n + 1) / 2);
     if (g.diag_opt) nt = (long long)g.tiles_m * (g.tiles_m - 1) / 2 + (g.tiles_m + 1) / 2;
     dim3 grid((unsigned)nt, (unsigned)splits, (unsigned)o.batch);
     // op(A) is M x K: not transposed -> stored [M][K] (m-major); transposed -> stored [K][M] (k-major)
