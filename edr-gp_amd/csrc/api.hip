@@ -303,6 +303,7 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
     const int64_t N = c->N;
     const int Wd = 2 * D + 1;
     const int np = c->nparts;
+    c->grad_serial = 0;                 // the workspaces are about to be overwritten
     // Working size.  The matrix kernels run their fast paths on whole 128-wide tiles and whole k-tiles only
     // (M = 1000 ran 1.4x slower than M = 1024).  An inducing set whose size is not a multiple of 128 is therefore
     // embedded in the next multiple: Mr real points plus M - Mr phantom points that are decoupled from
@@ -857,6 +858,36 @@ static int sparse_eval(Ctx* c, bool need_grad, bool need_post, SparseOut* out) {
         out->dnoise = dR;
     }
     tr.mark("host finishing");
+    // Kmm^-1, P and wv of this (data, Z, theta) stay in the workspaces: a posterior request that follows without
+    // any change of state is served from them (GPy's inference returns the posterior with every evaluation)
+    c->grad_serial = c->state_serial;
+    c->grad_lml = out->lml;
+    c->grad_M = M;
+    c->grad_Mr = Mr;
+    return EDRGP_OK;
+}
+
+// Posterior (woodbury vector / inverse) out of the workspaces of the bound+gradient evaluation that has just run
+// for the same state.
+static int posterior_from_last_gradient(Ctx* c) {
+    const int M = c->grad_M, Mr = c->grad_Mr;
+    const double* Kmmi = c->mats[MAT_KMMI].d();
+    const double* P = c->mats[MAT_P].d();
+    double* Tm = c->mats[MAT_T].d();
+    TRY(c->wv.reserve((size_t)Mr * sizeof(double)));
+    TRY(c->winv.reserve((size_t)Mr * Mr * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(c->wv.d(), c->tmpvec[3].d(), (size_t)Mr * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    if (M != Mr) {
+        TRY(combine3(c, M, 1.0, Kmmi, -1.0, P, 0.0, nullptr, 0.0, nullptr, Tm));
+        HIP_TRY(hipMemcpy2DAsync(c->winv.d(), (size_t)Mr * sizeof(double), Tm, (size_t)M * sizeof(double),
+                                 (size_t)Mr * sizeof(double), (size_t)Mr, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        TRY(combine3(c, M, 1.0, Kmmi, -1.0, P, 0.0, nullptr, 0.0, nullptr, c->winv.d()));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_post = true;
+    c->post_dense = false;
+    c->P = Mr;
     return EDRGP_OK;
 }
 
@@ -873,6 +904,7 @@ static int dense_eval(Ctx* c, bool need_grad, bool need_post, DenseOut* out) {
         return EDRGP_ERR_STATE;
     }
     if (c->comm) { set_error("the dense exact GP does not shard: replicas only"); return EDRGP_ERR_STATE; }
+    c->grad_serial = 0;                 // shares the M x M workspaces with the sparse path
     if (c->N > 46000) { set_error("dense exact GP limited to N <= 46000"); return EDRGP_ERR_INVALID; }
     const int n = (int)c->N, D = c->D, np = c->nparts, Wd = 2 * D + 1;
     const KSpec ks = make_kspec(c);
@@ -1114,6 +1146,7 @@ int edrgp_sync(edrgp_ctx* ctx) {
 
 int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
     CTX(ctx);
+    ++c->state_serial;
     if (!key) return EDRGP_ERR_INVALID;
     if (!std::strcmp(key, "chunk_rows")) c->chunk_rows = std::max<int64_t>(64, (int64_t)value);
     else if (!std::strcmp(key, "syrk_splits")) c->syrk_splits = (int)value;
@@ -1133,6 +1166,7 @@ int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
     else if (!std::strcmp(key, "chol_rhs")) c->chol_rhs = (value != 0.0);
     else if (!std::strcmp(key, "pad_inducing")) c->pad_inducing = (value != 0.0);
     else if (!std::strcmp(key, "gemm_pair")) c->gemm_pair = (value != 0.0);
+    else if (!std::strcmp(key, "posterior_reuse")) c->posterior_reuse = (value != 0.0);
     else if (!std::strcmp(key, "prebuild")) c->prebuild = (value != 0.0);
     else if (!std::strcmp(key, "syrk_xmap")) c->syrk_xmap = (value != 0.0);
     else if (!std::strcmp(key, "syrk_diag_opt")) c->syrk_diag_opt = (value != 0.0);
@@ -1159,6 +1193,7 @@ int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
 
 int edrgp_set_data(edrgp_ctx* ctx, const double* X, const double* y, int64_t N, int D) {
     CTX(ctx);
+    ++c->state_serial;
     if (!X || !y || N <= 0 || D <= 0 || D > EDRGP_MAX_DIM) { set_error("set_data: bad shape N=%lld D=%d", (long long)N, D); return EDRGP_ERR_INVALID; }
     if (c->have_Z && c->D != D) c->have_Z = false;
     if (c->have_kernel && c->D != D) c->have_kernel = false;
@@ -1194,6 +1229,7 @@ int edrgp_set_data(edrgp_ctx* ctx, const double* X, const double* y, int64_t N, 
 int edrgp_set_data_projected(edrgp_ctx* ctx, const double* Xbase, const double* y, int64_t N, int Dbase,
                              const double* W, int d) {
     CTX(ctx);
+    ++c->state_serial;
     if (!W || d <= 0 || d > EDRGP_MAX_DIM || Dbase <= 0 || N <= 0) { set_error("set_data_projected: bad shape"); return EDRGP_ERR_INVALID; }
     if (Xbase != nullptr) {
         if (!y) { set_error("set_data_projected: y is required with Xbase"); return EDRGP_ERR_INVALID; }
@@ -1238,6 +1274,7 @@ int edrgp_set_data_projected(edrgp_ctx* ctx, const double* Xbase, const double* 
 
 int edrgp_set_inducing(edrgp_ctx* ctx, const double* Z, int M) {
     CTX(ctx);
+    ++c->state_serial;
     if (!Z || M <= 0) { set_error("set_inducing: bad M=%d", M); return EDRGP_ERR_INVALID; }
     if (!c->have_data) { set_error("set_inducing: call set_data first (fixes D)"); return EDRGP_ERR_STATE; }
     const int D = c->D;
@@ -1263,6 +1300,7 @@ int edrgp_set_inducing(edrgp_ctx* ctx, const double* Z, int M) {
 int edrgp_set_kernel(edrgp_ctx* ctx, int nparts, const int* kinds, const double* variances,
                      const double* lengthscales, double noise_var) {
     CTX(ctx);
+    ++c->state_serial;
     if (!c->have_data) { set_error("set_kernel: call set_data first (fixes D)"); return EDRGP_ERR_STATE; }
     if (nparts < 1 || nparts > EDRGP_MAX_PARTS || !kinds || !variances || !lengthscales) {
         set_error("set_kernel: nparts must be 1..%d", EDRGP_MAX_PARTS);
@@ -1317,6 +1355,11 @@ int edrgp_sparse_lml_grad(edrgp_ctx* ctx, double* lml, double* dvar, double* dle
 
 int edrgp_sparse_posterior(edrgp_ctx* ctx, double* lml) {
     CTX(ctx);
+    if (c->posterior_reuse && c->grad_serial != 0 && c->grad_serial == c->state_serial) {
+        TRY(posterior_from_last_gradient(c));
+        if (lml) *lml = c->grad_lml;
+        return EDRGP_OK;
+    }
     SparseOut o;
     TRY(sparse_eval(c, false, true, &o));
     if (lml) *lml = o.lml;

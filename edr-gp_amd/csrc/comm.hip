@@ -43,6 +43,7 @@ int edrgp_comm_init(edrgp_ctx* ctx, int nranks, int rank, const void* id128) {
     if (!c || !id128 || nranks < 1 || rank < 0 || rank >= nranks) { set_error("comm_init: bad arguments"); return EDRGP_ERR_INVALID; }
     HIP_TRY(hipSetDevice(c->device));
     if (c->comm) { set_error("comm_init: communicator already attached"); return EDRGP_ERR_STATE; }
+    ++c->state_serial;
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof(id));
     ncclComm_t comm;
@@ -57,6 +58,7 @@ int edrgp_comm_init(edrgp_ctx* ctx, int nranks, int rank, const void* id128) {
 int edrgp_comm_destroy(edrgp_ctx* ctx) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     if (!c || !c->comm) return EDRGP_OK;
+    ++c->state_serial;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     ncclResult_t r = ncclCommDestroy(static_cast<ncclComm_t>(c->comm));

@@ -224,6 +224,12 @@ struct Ctx {
     bool syrk_diag_opt = true;        // Phi: diagonal tiles compute their 36 lower 16x16 blocks only
     bool syrk_xmap = true;            // Phi: split-major workgroup -> XCD map (la_gemm.hip)
     bool prebuild = true;             // gradient evaluations: K_nm build on the main stream beside phase 1 on the side stream
+    // posterior reuse: every mutator bumps state_serial; a bound+gradient evaluation that completed leaves
+    // Kmm^-1, P, wv of its (theta, Z, data) in the workspaces and records the serial it was computed for
+    uint64_t state_serial = 1, grad_serial = 0;
+    double grad_lml = 0.0;
+    int grad_M = 0, grad_Mr = 0;
+    bool posterior_reuse = true;
     bool gemm_pair = true;            // stable form's K_nm Li^T: column tiles paired (long, short) per workgroup
     bool pad_inducing = true;         // sparse evaluations: embed M inducing points in the next multiple of 128 (api.hip)
     int M_work = 0;                   // working size of the last sparse evaluation (>= M)

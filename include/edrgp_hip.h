@@ -95,6 +95,8 @@ int  edrgp_sync(edrgp_ctx* ctx);
  * "chol_rhs" (bound-only: right-hand side carried through the second factorisation, no explicit inverse),
  * "pad_inducing" (M > 256 not a multiple of 128: decoupled phantom inducing points up to the next multiple),
  * "gemm_pair" (stable form's K_nm Lm^-T: column tiles paired long + short per workgroup),
+ * "posterior_reuse" (edrgp_sparse_posterior right after a bound+gradient evaluation of the same state is
+ *  served from that evaluation's factors),
  * "mfma_kbuild", "kbuild_tile" (64 / 128),
  * "gemm_dephase", "tri_tile"; "side_cus" (CU-masked stream pair for bound-only evaluations, default 0 = off);
  * "trace" (host-side phase timing to stderr). */

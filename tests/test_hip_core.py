@@ -238,6 +238,46 @@ def test_padded_inducing_set(hip, N, M, D, kinds, mode):
     assert abs(res[1][0] - res[0][0]) <= 1e-11 * abs(res[0][0])
 
 
+@pytest.mark.parametrize("M", [96, 300])
+def test_posterior_reuses_last_gradient_evaluation(hip, M):
+    """A posterior request right after a bound+gradient evaluation of the same state is served from that
+    evaluation's workspaces (GPy returns the posterior with every inference call): same numbers as a full
+    posterior evaluation; any change of state in between turns the shortcut off."""
+    N, D = 1500, 5
+    X, y, Z = go.synthetic_problem(N, D, M, seed=40 + M)
+    kern = go.make_kernel(["RBF"], D, [dict(variance=1.1, lengthscale=0.7 * np.sqrt(D))])
+    hip.set_data(X, y)
+    hip.set_inducing(Z)
+    set_kernel(hip, kern, 0.05)
+    lml_g = hip.sparse_lml_grad()[0]
+    lml_p = hip.sparse_posterior()                       # shortcut
+    wv1, winv1 = hip.get("WV", M), hip.get("WINV", M * M)
+    mu1, var1 = hip.predict(X[:64])
+    jac1 = hip.predict_grad(X[:64])
+    assert lml_p == lml_g
+    try:
+        hip.set_option("posterior_reuse", 0)
+        hip.sparse_lml_grad()
+        lml_f = hip.sparse_posterior()                   # full evaluation
+    finally:
+        hip.set_option("posterior_reuse", 1)
+    wv2, winv2 = hip.get("WV", M), hip.get("WINV", M * M)
+    mu2, var2 = hip.predict(X[:64])
+    jac2 = hip.predict_grad(X[:64])
+    assert abs(lml_f - lml_g) <= 1e-13 * abs(lml_g)
+    assert np.array_equal(wv1, wv2) and np.array_equal(winv1, winv2)
+    assert np.array_equal(mu1, mu2) and np.array_equal(var1, var2) and np.array_equal(jac1, jac2)
+    # a change of state between the two calls: the posterior must be the one of the new state
+    hip.sparse_lml_grad()
+    kern2 = go.make_kernel(["RBF"], D, [dict(variance=0.8, lengthscale=1.1 * np.sqrt(D))])
+    set_kernel(hip, kern2, 0.08)
+    hip.sparse_posterior()
+    inf = go.vardtc_inference(kern2, X, Z, 0.08, y[:, None])
+    mu_ref, _ = go.raw_predict(kern2, X[:64], Z, inf["woodbury_vector"], inf["woodbury_inv"])
+    amp = max(1.0, np.linalg.cond(kern2.K(Z) + 1e-8 * np.eye(M)) / 1e6)
+    assert np.abs(hip.predict(X[:64])[0] - mu_ref[:, 0]).max() <= 1e-7 * amp * np.abs(mu_ref).max()
+
+
 def test_sparse_jitchol_retry_duplicate_inducing(hip):
     """Z with exact duplicates: Kmm + 1e-8 I is numerically singular for a wide RBF;
     the jitter ladder (GPy jitchol) must take over or succeed; result must be finite."""
