@@ -1072,7 +1072,8 @@ int syrk_tn(Ctx* c, const double* K, int64_t rows, int M, int ldk, double* Phi, 
     TRY(c->slabs.reserve((size_t)splits * slabStride * sizeof(double)));
     GemmOpts o;
     o.tri = 1;
-    o.tag = getenv("EDRGP_GEMM_STAMPS") ? 9 : 1;
+    static const bool want_stamps = (getenv("EDRGP_GEMM_STAMPS") != nullptr);      // diagnostic build of the kernel
+    o.tag = want_stamps ? 9 : 1;
     o.force_tile = tile;
     {
         ProfScope ps(c, EDRGP_PROF_SYRK);
