@@ -242,7 +242,7 @@ def main():
     if rank == 0 and N % 16 == 0 and M % 128 == 0:
         try:
             h.sync()
-            iso_ms, _ = h.dbg_syrk_variant(N, M, 0, 0, 5)
+            iso_ms, _ = h.dbg_syrk_time(N, M, 0, 5)
         except Exception:
             iso_ms = None
 

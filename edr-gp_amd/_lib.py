@@ -55,6 +55,8 @@ PROTOTYPES = {
                                  ctypes.c_int],
     "edrgp_set_inducing": [_ctx_p, _c_double_p, ctypes.c_int],
     "edrgp_set_kernel": [_ctx_p, ctypes.c_int, _c_int_p, _c_double_p, _c_double_p, ctypes.c_double],
+    "edrgp_kernel_matrix": [_ctx_p, ctypes.c_int, _c_int_p, _c_double_p, _c_double_p, _c_double_p, ctypes.c_int64,
+                            _c_double_p, ctypes.c_int64, ctypes.c_int, _c_double_p],
     "edrgp_sparse_lml": [_ctx_p, _c_double_p],
     "edrgp_sparse_lml_grad": [_ctx_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p],
     "edrgp_sparse_posterior": [_ctx_p, _c_double_p],
@@ -80,10 +82,7 @@ PROTOTYPES = {
     "edrgp_dbg_diag_stamps": [_ctx_p, _c_double_p, ctypes.c_int, _c_double_p],
     "edrgp_dbg_trtri": [_ctx_p, _c_double_p, _c_double_p, ctypes.c_int],
     "edrgp_dbg_syrk": [_ctx_p, _c_double_p, ctypes.c_int64, ctypes.c_int, _c_double_p],
-    "edrgp_dbg_syrk_variant": [_ctx_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                               _c_double_p, _c_double_p],
-    "edrgp_dbg_kernel_matrix": [_ctx_p, _c_double_p, ctypes.c_int64, _c_double_p, ctypes.c_int64, ctypes.c_int,
-                                _c_double_p],
+    "edrgp_dbg_syrk_time": [_ctx_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_double_p, _c_double_p],
     "edrgp_dbg_mfma_layout": [_ctx_p, _c_double_p, _c_double_p, _c_double_p],
     "edrgp_calib": [_ctx_p, _c_double_p, _c_double_p],
 }

@@ -80,6 +80,22 @@ class HipGP:
         check(self._lib.edrgp_set_kernel(self._ctx, len(kinds), codes.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
                                          dptr(var), dptr(ls), float(noise_var)))
         self.nparts = len(kinds)
+        self._kernel = (list(kinds), var.copy(), ls.copy())
+
+    def kernel_matrix(self, kinds, variances, lengthscales, X, X2=None):
+        """K(X, X2) (``X2=None``: K(X, X)) of the kernel given by value; stateless -- nothing resident on the
+        device (data, Z, hyper-parameters, posterior) is touched."""
+        X = as_f64(X)
+        D = X.shape[1]
+        codes = np.ascontiguousarray([KERN_CODES[k] for k in kinds], dtype=np.int32)
+        var = as_f64(variances).ravel()
+        ls = as_f64(lengthscales).reshape(len(kinds), D)
+        X2c = None if X2 is None else as_f64(X2)
+        n2 = X.shape[0] if X2c is None else X2c.shape[0]
+        out = np.empty((X.shape[0], n2))
+        check(self._lib.edrgp_kernel_matrix(self._ctx, len(kinds), codes.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
+                                            dptr(var), dptr(ls), dptr(X), X.shape[0], dptr(X2c), n2, D, dptr(out)))
+        return out
 
     # -- evaluations -------------------------------------------------------
     def sparse_lml(self):
@@ -233,20 +249,17 @@ class HipGP:
         check(self._lib.edrgp_dbg_syrk(self._ctx, dptr(K), K.shape[0], K.shape[1], dptr(out)))
         return out
 
-    def dbg_syrk_variant(self, N, M, variant=0, splits=0, reps=3, want_phi=False):
+    def dbg_syrk_time(self, N, M, splits=0, reps=3, want_phi=False):
+        """Average time (ms) of the production Phi = K^T K kernel alone on a device-generated K."""
         ms = ctypes.c_double(0.0)
         phi = np.empty((M, M)) if want_phi else None
-        check(self._lib.edrgp_dbg_syrk_variant(self._ctx, N, M, variant, splits, reps, ctypes.byref(ms), dptr(phi)))
+        check(self._lib.edrgp_dbg_syrk_time(self._ctx, N, M, splits, reps, ctypes.byref(ms), dptr(phi)))
         return ms.value, phi
 
     def dbg_kernel_matrix(self, X, X2=None):
-        X = as_f64(X)
-        n2 = X.shape[0] if X2 is None else X2.shape[0]
-        X2c = None if X2 is None else as_f64(X2)
-        out = np.empty((X.shape[0], n2))
-        check(self._lib.edrgp_dbg_kernel_matrix(self._ctx, dptr(X), X.shape[0], dptr(X2c), n2, X.shape[1],
-                                                dptr(out)))
-        return out
+        """K(X, X2) with the hyper-parameters of the last ``set_kernel`` (test convenience)."""
+        kinds, var, ls = self._kernel
+        return self.kernel_matrix(kinds, var, ls, X, X2)
 
     def dbg_mfma_layout(self, A16x4, B4x16):
         A = as_f64(A16x4)

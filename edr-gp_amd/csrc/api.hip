@@ -120,10 +120,10 @@ struct SideStream {
     ~SideStream() { swap(); }
     void swap() {
         std::swap(c->stream, c->stream2);
-        std::swap(c->red, c->red2);
-        std::swap(c->slabs, c->slabs2);
-        std::swap(c->ks_x, c->ks_x2);          // the side stream builds Kmm while the main one builds K_nm
-        std::swap(c->ks_xn, c->ks_xn2);
+        c->red.swap(c->red2);
+        c->slabs.swap(c->slabs2);
+        c->ks_x.swap(c->ks_x2);         // the side stream builds Kmm while the main one builds K_nm
+        c->ks_xn.swap(c->ks_xn2);
     }
     // while active c->stream IS the side stream and c->stream2 the main one
     int start_after_main() {
@@ -1113,7 +1113,7 @@ int edrgp_ctx_destroy(edrgp_ctx* ctx) {
     if (c->comm) edrgp_comm_destroy(ctx);
     DBuf* bufs[] = {&c->ptw, &c->Xbase, &c->X, &c->y, &c->Z, &c->Xt, &c->Zt, &c->Xq, &c->g2, &c->Knm32, &c->T32, &c->S2f, &c->Xq32,
                     &c->ks32_x, &c->ks32_z, &c->ks32_xn, &c->ks32_zn, &c->invl, &c->wv, &c->winv, &c->Knm, &c->W, &c->T, &c->slabs,
-                    &c->bpart, &c->scal, &c->info, &c->gt_nm, &c->gt_mm, &c->panel, &c->trtri_ws, &c->dinv, &c->red};
+                    &c->bpart, &c->scal, &c->info, &c->gt_nm, &c->gt_mm, &c->panel, &c->trtri_ws, &c->dinv, &c->red, &c->lbaug, &c->xs_in};
     for (DBuf* b : bufs) b->release();
     for (auto& m : c->mats) m.release();
     for (auto& v : c->tmpvec) v.release();
@@ -1388,29 +1388,29 @@ int edrgp_dense_posterior(edrgp_ctx* ctx, double* lml) {
     return EDRGP_OK;
 }
 
+// test inputs go through a grow-only buffer owned by the context (no hipMalloc / hipFree per call)
+static int upload_inputs(Ctx* c, const double* Xs, int64_t Ns) {
+    if (!c->have_data) { set_error("predict: no data (the input dimension is fixed by set_data)"); return EDRGP_ERR_STATE; }
+    TRY(c->xs_in.reserve((size_t)Ns * c->D * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(c->xs_in.d(), Xs, (size_t)Ns * c->D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    return EDRGP_OK;
+}
+
 int edrgp_predict(edrgp_ctx* ctx, const double* Xs, int64_t Ns, double* mean, double* var) {
     CTX(ctx);
     if (!Xs || Ns <= 0) { set_error("predict: bad input"); return EDRGP_ERR_INVALID; }
-    DBuf xs;
-    TRY(xs.reserve((size_t)Ns * c->D * sizeof(double)));
-    hipError_t e = hipMemcpyAsync(xs.d(), Xs, (size_t)Ns * c->D * sizeof(double), hipMemcpyHostToDevice, c->stream);
-    int s = (e == hipSuccess) ? predict_rows(c, xs.d(), Ns, mean, var, nullptr) : EDRGP_ERR_HIP;
-    (void)hipStreamSynchronize(c->stream);
-    xs.release();
-    if (e != hipSuccess) set_error("predict: H2D copy failed: %s", hipGetErrorString(e));
+    TRY(upload_inputs(c, Xs, Ns));
+    const int s = predict_rows(c, c->xs_in.d(), Ns, mean, var, nullptr);
+    (void)hipStreamSynchronize(c->stream);          // Xs is a borrowed host pointer
     return s;
 }
 
 int edrgp_predict_grad(edrgp_ctx* ctx, const double* Xs, int64_t Ns, double* grad) {
     CTX(ctx);
     if (!Xs || Ns <= 0 || !grad) { set_error("predict_grad: bad input"); return EDRGP_ERR_INVALID; }
-    DBuf xs;
-    TRY(xs.reserve((size_t)Ns * c->D * sizeof(double)));
-    hipError_t e = hipMemcpyAsync(xs.d(), Xs, (size_t)Ns * c->D * sizeof(double), hipMemcpyHostToDevice, c->stream);
-    int s = (e == hipSuccess) ? predict_rows(c, xs.d(), Ns, nullptr, nullptr, grad) : EDRGP_ERR_HIP;
+    TRY(upload_inputs(c, Xs, Ns));
+    const int s = predict_rows(c, c->xs_in.d(), Ns, nullptr, nullptr, grad);
     (void)hipStreamSynchronize(c->stream);
-    xs.release();
-    if (e != hipSuccess) set_error("predict_grad: H2D copy failed: %s", hipGetErrorString(e));
     return s;
 }
 
@@ -1611,31 +1611,27 @@ int edrgp_dbg_syrk(edrgp_ctx* ctx, const double* K, int64_t N, int M, double* Ph
     return s;
 }
 
-// Times `reps` launches of a Phi = K^T K kernel variant on a device-generated K
-// (uniform [0,1) pattern); variant 0 = production path.  Phi_out (M x M) optional.
-int edrgp_dbg_syrk_variant(edrgp_ctx* ctx, int64_t N, int M, int variant, int splits, int reps, double* avg_ms,
-                           double* Phi_out) {
+// Times `reps` launches of the production Phi = K^T K kernel alone on a device-generated K
+// (uniform [0,1) pattern; splits < 0: constant data).  Phi_out (M x M) optional.
+int edrgp_dbg_syrk_time(edrgp_ctx* ctx, int64_t N, int M, int splits, int reps, double* avg_ms, double* Phi_out) {
     CTX(ctx);
-    if (N <= 0 || N % 16 || M % 128 || reps < 1) { set_error("dbg_syrk_variant: need N %% 16 == 0, M %% 128 == 0"); return EDRGP_ERR_INVALID; }
+    if (N <= 0 || N % 16 || M % 128 || reps < 1) { set_error("dbg_syrk_time: need N %% 16 == 0, M %% 128 == 0"); return EDRGP_ERR_INVALID; }
     TRY(c->Knm.reserve((size_t)N * M * sizeof(double)));
     TRY(c->mats[MAT_PHI].reserve(((size_t)M * M + M + 8) * sizeof(double)));
     c->knm_train_valid = false;
-    TRY(fill_pattern(c, c->Knm.d(), (size_t)N * M, splits < 0 ? 0ULL : 12345ULL));   // splits < 0: constant data probe
+    c->grad_serial = 0;
+    TRY(fill_pattern(c, c->Knm.d(), (size_t)N * M, splits < 0 ? 0ULL : 12345ULL));
     if (splits < 0) splits = 0;
     double* Phi = c->mats[MAT_PHI].d();
     const int saved = c->syrk_splits;
     c->syrk_splits = splits;
-    auto run = [&]() -> int {
-        if (variant == 0) return syrk_tn(c, c->Knm.d(), N, M, M, Phi, M, false);
-        return syrk_variant(c, c->Knm.d(), (int)N, M, M, variant, splits, Phi);
-    };
-    int s = run();
+    int s = syrk_tn(c, c->Knm.d(), N, M, M, Phi, M, false);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (s == EDRGP_OK) {
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, c->stream));
-        for (int r = 0; r < reps && s == EDRGP_OK; ++r) s = run();
+        for (int r = 0; r < reps && s == EDRGP_OK; ++r) s = syrk_tn(c, c->Knm.d(), N, M, M, Phi, M, false);
         HIP_TRY(hipEventRecord(e1, c->stream));
         HIP_TRY(hipEventSynchronize(e1));
         float ms = 0.f;
@@ -1650,27 +1646,50 @@ int edrgp_dbg_syrk_variant(edrgp_ctx* ctx, int64_t N, int M, int variant, int sp
     return s;
 }
 
-int edrgp_dbg_kernel_matrix(edrgp_ctx* ctx, const double* X, int64_t N, const double* X2, int64_t N2, int D,
-                            double* K) {
+// kern.K(X, X2) of a kernel given by value (GPy kern.K): nothing resident is touched -- the
+// training data, Z, the hyper-parameters and the posterior of the context stay as they are.
+int edrgp_kernel_matrix(edrgp_ctx* ctx, int nparts, const int* kinds, const double* variances,
+                        const double* lengthscales, const double* X, int64_t N, const double* X2, int64_t N2,
+                        int D, double* K) {
     CTX(ctx);
-    if (!c->have_kernel || D != c->D) { set_error("dbg_kernel_matrix: set_kernel first, D must match"); return EDRGP_ERR_STATE; }
+    if (nparts < 1 || nparts > EDRGP_MAX_PARTS || !kinds || !variances || !lengthscales || !X || !K || N <= 0 ||
+        D <= 0 || D > EDRGP_MAX_DIM || (X2 != nullptr && N2 <= 0)) {
+        set_error("kernel_matrix: bad argument");
+        return EDRGP_ERR_INVALID;
+    }
     const bool same = (X2 == nullptr);
     const int64_t n2 = same ? N : N2;
-    DBuf dX, dX2, dK;
+    if (n2 > 0x7fffffffLL) { set_error("kernel_matrix: too many columns"); return EDRGP_ERR_INVALID; }
+    KSpec ks;
+    ks.nparts = nparts;
+    ks.D = D;
+    std::vector<double> invl((size_t)nparts * D);
+    for (int p = 0; p < EDRGP_MAX_PARTS; ++p) { ks.kind[p] = 0; ks.var[p] = 0.0; }
+    for (int p = 0; p < nparts; ++p) {
+        if (kinds[p] < 0 || kinds[p] > 2 || !(variances[p] > 0.0)) { set_error("kernel_matrix: bad kernel part %d", p); return EDRGP_ERR_INVALID; }
+        ks.kind[p] = kinds[p];
+        ks.var[p] = variances[p];
+        for (int q = 0; q < D; ++q) {
+            const double l = lengthscales[(size_t)p * D + q];
+            if (!(l > 0.0)) { set_error("kernel_matrix: lengthscale must be positive"); return EDRGP_ERR_INVALID; }
+            invl[(size_t)p * D + q] = 1.0 / l;
+        }
+    }
+    DBuf dX, dX2, dK, dL;
     TRY(dX.reserve((size_t)N * D * sizeof(double)));
     TRY(dK.reserve((size_t)N * n2 * sizeof(double)));
+    TRY(dL.reserve(invl.size() * sizeof(double)));
     HIP_TRY(hipMemcpy(dX.d(), X, (size_t)N * D * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dL.d(), invl.data(), invl.size() * sizeof(double), hipMemcpyHostToDevice));
     if (!same) {
         TRY(dX2.reserve((size_t)N2 * D * sizeof(double)));
         HIP_TRY(hipMemcpy(dX2.d(), X2, (size_t)N2 * D * sizeof(double), hipMemcpyHostToDevice));
     }
-    const KSpec ks = make_kspec(c);
-    int s = kernel_matrix(c, ks, dX.d(), N, same ? dX.d() : dX2.d(), (int)n2, dK.d(), (int)n2, same ? 1 : 0, 0.0,
-                          nullptr, nullptr);
-    if (s == EDRGP_OK && hipStreamSynchronize(c->stream) != hipSuccess) { set_error("dbg_kernel_matrix: kernel failed"); s = EDRGP_ERR_HIP; }
-    if (s == EDRGP_OK) HIP_TRY(hipMemcpy(K, dK.d(), (size_t)N * n2 * sizeof(double), hipMemcpyDeviceToHost));
-    dX.release(); dX2.release(); dK.release();
-    return s;
+    ks.invl = dL.d();
+    TRY(kernel_matrix(c, ks, dX.d(), N, same ? dX.d() : dX2.d(), (int)n2, dK.d(), (int)n2, same ? 1 : 0, 0.0, nullptr, nullptr));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(K, dK.d(), (size_t)N * n2 * sizeof(double), hipMemcpyDeviceToHost));
+    return EDRGP_OK;
 }
 
 int edrgp_dbg_mfma_layout(edrgp_ctx* ctx, const double* A16x4, const double* B4x16, double* C16x16) {

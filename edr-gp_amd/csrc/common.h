@@ -42,6 +42,11 @@ struct KSpec {                       // passed by value to device kernels
 struct DBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    DBuf() = default;
+    DBuf(const DBuf&) = delete;
+    DBuf& operator=(const DBuf&) = delete;
+    ~DBuf() { release(); }           // every exit path of a function holding a local DBuf frees it
+    void swap(DBuf& o) { void* tp = p; p = o.p; o.p = tp; size_t tb = bytes; bytes = o.bytes; o.bytes = tb; }
     int reserve(size_t need);        // grow-only (hipMalloc)
     void release();
     double* d() const { return static_cast<double*>(p); }
@@ -130,9 +135,7 @@ int syrk_tn(Ctx* c, const double* K, int64_t rows, int M, int ldk, double* Phi, 
 
 int pick_syrk_splits(Ctx* c, long long nt, int kt, int64_t rows, int M, int tile, int elem_bytes);
 int slab_reduce_mirror(Ctx* c, const double* slabs, int splits, long long slabStride, int M, double* Phi);
-// experimental variants (exp_syrk.hip)
-int syrk_variant(Ctx* c, const double* K, int rows, int M, int ld, int variant, int splits, double* Phi);
-int fill_pattern(Ctx* c, double* K, size_t n, unsigned long long seed);
+int fill_pattern(Ctx* c, double* K, size_t n, unsigned long long seed);   // device-generated test operand (la_vec.hip)
 
 // ------------------------------------------------------- Cholesky / triangular
 // In-place lower Cholesky of the n x n matrix A (row-major, lda); the strict
@@ -286,6 +289,7 @@ struct Ctx {
     bool post_dense = false;
     int P = 0;                        // number of posterior basis points
     DBuf wv, winv;
+    DBuf xs_in;                       // test inputs of edrgp_predict / edrgp_predict_grad (grow-only)
 
     // workspace
     DBuf Knm, W, T;                   // chunk x M

@@ -268,4 +268,22 @@ int combine3(Ctx* c, int n, double a, const double* A, double b, const double* B
     return EDRGP_OK;
 }
 
+// Device-generated operand for timing probes (edrgp_dbg_syrk_time): seed 0 = constant data,
+// otherwise uniform [0, 1) values (like kernel-matrix entries) from a splitmix-style hash of the index.
+__global__ void fill_pattern_kernel(double* __restrict__ K, size_t n, unsigned long long seed) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        unsigned long long x = (i + 1) * 0x9E3779B97F4A7C15ULL + seed;
+        x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 32;
+        K[i] = (seed == 0ULL) ? 0.5 : (double)(x >> 11) * (1.0 / 9007199254740992.0);
+    }
+}
+
+int fill_pattern(Ctx* c, double* K, size_t n, unsigned long long seed) {
+    hipLaunchKernelGGL(fill_pattern_kernel, dim3(2048), dim3(256), 0, c->stream, K, n, seed);
+    HIP_TRY(hipGetLastError());
+    return EDRGP_OK;
+}
+
 }  // namespace edrgp

@@ -128,14 +128,11 @@ def _device_K(kern, X, X2):
     X = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
     if X.ndim != 2 or X.shape[1] != kern.input_dim:
         raise ValueError("X must be (n, %d)" % kern.input_dim)
-    ctx = shared_context()
-    ctx.claim(None)
-    h = ctx.hip
-    h.set_data(X, np.zeros(X.shape[0]))
     parts = kern.parts
-    h.set_kernel([p.kind for p in parts], [p.variance for p in parts],
-                 np.array([p.expanded_lengthscale() for p in parts]), 1.0)
-    return h.dbg_kernel_matrix(X, None if X2 is None else np.asarray(X2, dtype=np.float64))
+    # stateless native call: the shared context's resident data / posterior are not touched
+    return shared_context().hip.kernel_matrix([p.kind for p in parts], [p.variance for p in parts],
+                                              np.array([p.expanded_lengthscale() for p in parts]), X,
+                                              None if X2 is None else np.asarray(X2, dtype=np.float64))
 
 
 def from_names(kernels, kernel_options, input_dim):

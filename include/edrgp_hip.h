@@ -121,6 +121,13 @@ int  edrgp_set_kernel(edrgp_ctx* ctx, int nparts, const int* kinds,
                       const double* variances, const double* lengthscales,
                       double noise_var);
 
+/* GPy kern.K(X, X2) (X2 == NULL: K(X, X), exact zeros of r on the diagonal) for a kernel passed by value:
+ * what edrgp's tests build their targets with (edrgp/tests/test_edr.py:40-42, k.K(X)).  Stateless: the
+ * resident data, inducing inputs, hyper-parameters and posterior of the context are not touched. */
+int  edrgp_kernel_matrix(edrgp_ctx* ctx, int nparts, const int* kinds, const double* variances,
+                         const double* lengthscales, const double* X, int64_t N, const double* X2, int64_t N2,
+                         int D, double* K);
+
 /* GPy VarDTC.inference (sparse fit, one call per optimiser iteration):
  * Titsias bound only. */
 int  edrgp_sparse_lml(edrgp_ctx* ctx, double* lml);
@@ -181,11 +188,8 @@ int  edrgp_dbg_potrf(edrgp_ctx* ctx, double* A, int n, int* info);
 int  edrgp_dbg_diag_stamps(edrgp_ctx* ctx, const double* A64x64, int do_chol, double* stamps6);
 int  edrgp_dbg_trtri(edrgp_ctx* ctx, const double* L, double* Linv, int n);
 int  edrgp_dbg_syrk(edrgp_ctx* ctx, const double* K, int64_t N, int M, double* Phi);
-/* times a Phi = K^T K kernel variant on a device-generated K (0 = production kernel) */
-int  edrgp_dbg_syrk_variant(edrgp_ctx* ctx, int64_t N, int M, int variant, int splits, int reps,
-                            double* avg_ms, double* Phi_out);
-int  edrgp_dbg_kernel_matrix(edrgp_ctx* ctx, const double* X, int64_t N,
-                             const double* X2, int64_t N2, int D, double* K);
+/* times the production Phi = K^T K kernel alone on a device-generated K (bench.py "isolated" figure) */
+int  edrgp_dbg_syrk_time(edrgp_ctx* ctx, int64_t N, int M, int splits, int reps, double* avg_ms, double* Phi_out);
 int  edrgp_dbg_mfma_layout(edrgp_ctx* ctx, const double* A16x4, const double* B4x16, double* C16x16);
 /* fp64 MFMA issue-rate microbenchmark: achieved TFLOP/s of back-to-back
  * v_mfma_f64_16x16x4_f64 on every SIMD, and HBM copy bandwidth in GB/s. */

@@ -27,7 +27,7 @@ The reference holds NO golden vectors or known-answer values for this path
 (``edrgp/tests/test_edr.py:33-117`` are five loose end-to-end invariants), and
 GPy cannot be run here, so parity with GPy itself is **unpinned**.  The oracle
 is pinned instead against independent known answers that exist in this
-container (``tests/test_oracle.py``): scikit-learn's exact GP
+container (``tests/test_golden.py``): scikit-learn's exact GP
 log-marginal-likelihood / posterior (|d| ~ 1e-13), the VarDTC bound with Z = X
 versus the exact LML, the variational lower-bound property, central finite
 differences of the bound for every hyper-parameter and for Z, and finite

@@ -1,7 +1,7 @@
 """Random-shape parity fuzz against the CPU oracle (bound, gradients, posterior mean / Jacobian)."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import gp_oracle as go
 from edrgp_amd.backend import HipGP
 kinds_all = ["RBF", "Matern32", "Matern52"]

@@ -1,7 +1,7 @@
 """Random-shape parity fuzz of the dense exact GP and of the device-side EDR step against the oracle."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import gp_oracle as go
 from edrgp_amd.backend import HipGP
 kinds_all = ["RBF", "Matern32", "Matern52"]

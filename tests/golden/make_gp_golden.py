@@ -20,7 +20,7 @@ from sklearn.gaussian_process.kernels import RBF, ConstantKernel, Matern, WhiteK
 SK_KERN = {"RBF": lambda l: RBF(l), "Matern52": lambda l: Matern(l, nu=2.5), "Matern32": lambda l: Matern(l, nu=1.5)}
 out = {}
 case_id = 0
-for seed in (0, 1):
+for seed in (0, 1, 2):
     for kind in ("RBF", "Matern52", "Matern32"):
         for (N, M, D) in ((256, 32, 4), (512, 64, 8)):
             X, y, Z = go.synthetic_problem(N, D, M, seed=seed)
@@ -51,6 +51,11 @@ for seed in (0, 1):
             out[p + "bound"] = inf["log_marginal"]
             out[p + "phi_sum_trace"] = np.array([st["Phi"].sum(), np.trace(st["Phi"]), st["b"].sum()])
             out[p + "wv"] = inf["woodbury_vector"][:, 0]
+            # fingerprints of the M x M intermediates: [sum, trace, Frobenius norm] and the diagonals
+            fp = lambda A: np.array([A.sum(), np.trace(A), np.linalg.norm(A)])   # noqa: E731
+            out[p + "kmm_fp"], out[p + "lm_fp"], out[p + "lb_fp"] = fp(inf["Kmm"]), fp(inf["Lm"]), fp(inf["LB"])
+            out[p + "knm_fp"] = np.array([inf["psi1"].sum(), np.linalg.norm(inf["psi1"])])
+            out[p + "lm_diag"], out[p + "lb_diag"] = np.diag(inf["Lm"]).copy(), np.diag(inf["LB"]).copy()
             out[p + "pred_mean"], out[p + "pred_var"], out[p + "pred_jac"] = mu[:, 0], v[:, 0], jac
             out[p + "grad"] = np.array([kg[0][0], kg[0][1][0], dn])
             out[p + "dZ"] = dZ

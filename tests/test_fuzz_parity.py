@@ -1,6 +1,6 @@
 """Random-shape parity sweep against the CPU oracle through the C ABI: ragged N / M / D (1..44 features,
 1..199 inducing inputs), single and sum kernels of the three kinds, tiny row chunks, automatic and
-stable statistics (tools/fuzz.py holds the generator and the conditioning-aware tolerances)."""
+stable statistics (tests/fuzz/fuzz.py holds the generator and the conditioning-aware tolerances)."""
 import os
 import sys
 
@@ -8,7 +8,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz"))
 
 
 @pytest.mark.parametrize("seed", [0, 7])

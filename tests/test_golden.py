@@ -44,7 +44,10 @@ def test_oracle_reproduces_golden(c):
     kg, dn, dZ = go.sparse_gradients(kern, c["X"], c["Z"], inf)
     assert rel([kg[0][0], kg[0][1][0], dn], c["grad"]) < 1e-9
     mu, _ = go.raw_predict(kern, c["Xs"], c["Z"], inf["woodbury_vector"], inf["woodbury_inv"])
-    assert rel(mu[:, 0], c["pred_mean"]) < 1e-9
+    assert rel(inf["woodbury_vector"][:, 0], c["wv"]) < 1e-9
+    st = go.gram_stats(kern, c["X"], c["Z"], c["y"][:, None])
+    assert rel([st["Phi"].sum(), np.trace(st["Phi"]), st["b"].sum()], c["phi_sum_trace"]) < 1e-12
+    assert rel(np.diag(inf["Lm"]), c["lm_diag"]) < 1e-10 and rel(np.diag(inf["LB"]), c["lb_diag"]) < 1e-10
     dense = go.exact_inference(kern, c["X"], noise, c["y"][:, None])
     # c["dense_lml"][1] is scikit-learn's independent value
     assert abs(dense["log_marginal"] - c["dense_lml"][1]) < 1e-9 * abs(c["dense_lml"][1])
@@ -64,7 +67,25 @@ def test_hip_reproduces_golden(hip, c):
     g = np.array([dvar[0], dlen[0].sum(), dnoise])
     assert np.abs(g - c["grad"]).max() <= 1e-7 * np.abs(c["grad"]).max()
     assert np.abs(dZ - c["dZ"]).max() <= 1e-6 * np.abs(c["dZ"]).max()
+    # the intermediates of the same evaluation: Kmm, K_nm, Lm, LB fingerprints, and the row statistics
+    fp = lambda A: np.array([A.sum(), np.trace(A), np.linalg.norm(A)])   # noqa: E731
+    hip.set_option("stats_mode", 1)              # Phi = K_mn K_nm and b = K_mn y are defined by the Gram form
+    try:
+        lml1 = hip.sparse_lml_grad()[0]
+        assert abs(lml1 - c["bound"][0, 0]) <= 1e-10 * abs(c["bound"][0, 0])
+        Phi, b = hip.get("PHI", (M, M)), hip.get("BVEC", (M,))
+        assert rel([Phi.sum(), np.trace(Phi), b.sum()], c["phi_sum_trace"]) < 1e-12
+        Lm, LB = hip.get("LM", (M, M)), hip.get("LB", (M, M))
+        assert rel(fp(Lm), c["lm_fp"]) < 1e-10 and rel(np.diag(Lm), c["lm_diag"]) < 1e-9
+        assert rel(fp(LB), c["lb_fp"]) < 1e-10 and rel(np.diag(LB), c["lb_diag"]) < 1e-9
+        Knm = hip.get("KNM", (N, M))
+        assert rel([Knm.sum(), np.linalg.norm(Knm)], c["knm_fp"]) < 1e-12
+    finally:
+        hip.set_option("stats_mode", 0)
+    Kmm = hip.kernel_matrix([kind], [var], np.full((1, D), ls), c["Z"]) + 1e-8 * np.eye(M)
+    assert rel(fp(Kmm), c["kmm_fp"]) < 1e-12
     hip.sparse_posterior()
+    assert rel(hip.get("WV", (M,)), c["wv"]) < 1e-7
     mu, v = hip.predict(c["Xs"])
     assert rel(mu, c["pred_mean"]) < 1e-8
     assert np.abs(v - c["pred_var"]).max() < 1e-7
@@ -138,3 +159,25 @@ def test_base_block_and_utils_match_reference(edr_gold):
     assert close(ort_space(edr_gold["svr_V"]), edr_gold["ort"])
     # float n_components: the reference raises NameError (edrgp/utils.py:148-150); here it works
     assert SVDTransformer(n_components=0.9).fit(edr_gold["svd_in"]).components_.shape[0] >= 1
+
+
+def test_iterative_edr_matches_reference_on_gp_gradients(monkeypatch):
+    """iter_golden.npz (tests/golden/make_iter_golden.py): the reference's iterative EDR with the adaptive step
+    0.99 on the data of its own test_iterative, fed with GP gradients.  This repository's EDR layer, driven by
+    the same (oracle-answered) GP, must keep the same 3 directions after the same 3 iterations."""
+    from oracle_evaluator import OracleEvaluator
+    from edrgp_amd import models
+    from edrgp_amd.edr import EffectiveDimensionalityReduction
+    from edrgp_amd.gp_model import GaussianProcessRegressor
+    from edrgp_amd.utils import SVDTransformer, discrepancy
+    monkeypatch.setattr(models, "HipEvaluator", lambda device=None: OracleEvaluator())
+    g = np.load(os.path.join(GOLD, "iter_golden.npz"), allow_pickle=False)
+    edr = EffectiveDimensionalityReduction(GaussianProcessRegressor(['RBF'], [{'ARD': True}]), SVDTransformer(),
+                                           n_components=None, step=0.99, normalize=False)
+    edr.fit(g["X"], g["y"])
+    assert edr.num_iter == int(g["num_iter"]) == 3
+    assert edr.components_.shape == (3, 10)
+    assert close(edr._first_gradients_, g["first_gradients"], 1e-7)
+    assert close(edr.components_, g["components"], 1e-6)
+    assert close(np.atleast_1d(edr.subspace_variance_ratio_), g["subspace_variance_ratio"], 1e-6)
+    assert discrepancy(g["B"], edr.components_.T) < 1e-1          # upstream's own assertion

@@ -94,29 +94,33 @@ def test_scaling(mean):
     assert np.allclose(x1, x2)
 
 
-def _sparse_B(rng, nrow, ncol, density):
-    B = rng.standard_normal((nrow, ncol)) * (rng.random((nrow, ncol)) < density)
-    return B
-
-
 @pytest.mark.parametrize("n_components,step", [(3, 1), (None, 0.99)])
-def test_iterative_edr_recovers_subspace(n_components, step):
-    """edrgp/tests/test_edr.py:120-141 (disabled upstream): ARD RBF, N=300, D=10,
-    3 true directions; iterative EDR recovers the subspace (discrepancy < 0.1... relaxed to 0.2)."""
-    np.random.seed(1)
-    rng = np.random.default_rng(1)
+def test_iterative(n_components, step):
+    """edrgp/tests/test_edr.py:120-133 (shipped commented out upstream), with upstream's own set-up and
+    assertions: beta inputs 300 x 10, B = qr(random_sparse(10, 3, density 0.3, random_state 0)),
+    y = get_edr_target(X B, 0.1), ARD RBF GP, SVDTransformer, normalize=False; the iterative EDR must end
+    with exactly 3 directions, discrepancy < 0.1, variance ratios sorted.
+
+    Round 1 ran a variant (PCA() + normalize=True) and relaxed the assertions when it kept all 10 directions.
+    Diagnosis (round 2, CPU, the reference's own EDR classes imported from /root/reference and driven by the
+    oracle-backed GP on identical data): with upstream's set-up the reference and this repository's EDR layer
+    give the same result -- 3 x 10 components, discrepancy 0.026 (step 1) / 0.034 (step 0.99), 7 / 3 iterations
+    -- while with PCA() + normalize=True BOTH keep 10 directions at step 0.99: PCA centres the gradient matrix,
+    so the cumulative-variance rule of _select_n_components (edrgp/base.py:498-509) sees the variance about the
+    mean gradient and never reaches 0.99 before the last direction.  It was the test that deviated, not
+    `_select_n_components`; the assertions are upstream's again."""
+    from scipy.sparse import random as random_sparse
+    np.random.seed(0)
     X = get_beta_inputs(300, 10)
-    B = np.linalg.qr(rng.standard_normal((10, 3)))[0]
-    y = get_edr_target(X @ B)
-    edr = EffectiveDimensionalityReduction(GaussianProcessRegressor(kernels="RBF", kernel_options={"ARD": True}),
-                                           PCA(), n_components, step, True)
+    B = np.linalg.qr(random_sparse(10, 3, density=0.3, random_state=0).toarray())[0]
+    y = get_edr_target(X.dot(B), 0.1)
+    gp_model = GaussianProcessRegressor(['RBF'], [{'ARD': True}])
+    edr = EffectiveDimensionalityReduction(gp_model, SVDTransformer(), n_components=n_components, step=step,
+                                           normalize=False)
     edr.fit(X, y)
-    comps = edr.components_ / np.linalg.norm(edr.components_, axis=1, keepdims=True)
-    if n_components is not None:
-        assert comps.shape[0] == n_components        # directions were dropped down to the target
+    assert discrepancy(B, edr.components_.T) < 1e-1
+    assert edr.components_.shape[0] == 3
     assert np.all(edr.subspace_variance_ratio_ == np.sort(edr.subspace_variance_ratio_)[::-1])
-    Q = np.linalg.qr(comps.T)[0]                     # span of every kept direction
-    assert discrepancy(B, Q) < 0.2
 
 
 def test_get_gradients_shapes_and_sparse_estimator():
