@@ -21,7 +21,7 @@ partials are sum-all-reduced over RCCL once per evaluation.
 The same JSON line carries the log-ml evals/sec figure, the roofline of the
 dominant kernel (the fp64 MFMA syrk Phi = K_mn K_nm, timed with HIP events on the
 library's stream inside the timed region) and a CPU baseline (the numpy/scipy
-oracle, i.e. GPy's operation sequence, on a bounded row sample).
+oracle, i.e. GPy's operation sequence: one full-size bound evaluation, the rest from row samples).
 """
 from __future__ import annotations
 
@@ -40,15 +40,26 @@ FP64_MFMA_SPEC_TFLOPS = 78.6      # AMD public MI355X fp64 matrix peak; the loca
 ITERS_PER_FIT = 50
 
 
-def synthetic(N, D, M, seed, z_seed=0):
-    """X ~ N(0, I); y = tanh(X w) + 0.05 eps standardised; Z = first-shard rows."""
+RANK0_SEED = 1000
+
+
+def _rows(N, D, seed):
     rng = np.random.default_rng(seed)
     X = rng.standard_normal((N, D))
     y = np.tanh(X @ (np.ones(D) / np.sqrt(D))) + 0.05 * rng.standard_normal(N)
-    y = (y - y.mean()) / y.std()
-    zr = np.random.default_rng(z_seed)
-    Xz = zr.standard_normal((max(N, M), D))          # identical on every rank
-    Z = Xz[zr.permutation(Xz.shape[0])[:M]].copy()
+    return rng, X, (y - y.mean()) / y.std()
+
+
+def synthetic(N, D, M, seed, z_seed=RANK0_SEED):
+    """X ~ N(0, I); y = tanh(X w) + 0.05 eps standardised; Z = X[perm[:M]] (GPy
+    SparseGPRegression's rule) taken from RANK 0's rows, so every rank of a sharded run holds the same Z:
+    a rank whose seed is not z_seed regenerates rank 0's rows just for that."""
+    rng, X, y = _rows(N, D, seed)
+    if seed == z_seed:
+        Z = X[rng.permutation(N)[:M]].copy()
+    else:
+        rz, Xz, _ = _rows(N, D, z_seed)
+        Z = Xz[rz.permutation(N)[:M]].copy()
     return X, y, Z
 
 
@@ -105,43 +116,77 @@ def sharding_check(h, dist, rank, world, local_rank):
     return res
 
 
-def cpu_baseline(N_sample, M, D, kind, iters):
-    """The CPU path timed beside the GPU one: the oracle (GPy's LAPACK/BLAS call
-    sequence restated in numpy/scipy) on a bounded row sample, all host cores."""
+def cpu_baseline(N, M, D, kind, iters, sample_rows=(4000, 12000), full_bound=True):
+    """The CPU path timed beside the GPU one, on the host cores of the GPU box: the oracle (GPy's LAPACK/BLAS
+    call sequence restated in numpy/scipy, `kind` = "port").  Bounded to about a minute of CPU work:
+      * ONE bound evaluation at the full size (N of N rows), all cores  -> log-ml evals/s at the stated config;
+      * bound+gradient evaluation and the predict + predict_gradient pass at two row samples, all cores; the time
+        is linear in the rows plus a rows-independent O(M^3) part, so the two samples give both and the full-size
+        time is a + b N (the round-1 figure divided a 4 000-row time by 4 000 rows, which charged the O(M^3) part
+        25 times too often);
+      * the bound at the same two samples on ONE thread -> per-core figure, same model.
+    value = N / (iters x t_eval(N) + t_bound(N) + t_predict(N)), the step bench.py times on the GPU."""
     from oracle import gp_oracle as go
     from edrgp_amd.utils import effective_cpus
-    X, y, Z = synthetic(N_sample, D, M, seed=123)
+    from threadpoolctl import threadpool_limits
+    X, y, Z = synthetic(N, D, M, seed=RANK0_SEED)
     kern = go.make_kernel([kind], D, [dict(variance=1.0, lengthscale=np.sqrt(D))])
     Y = y[:, None]
     # BLAS threads = the cores the process may really use (affinity capped by the cgroup quota): an
-    # oversubscribed pool (one thread per visible core of the host) would only slow the CPU path down
-    _cpu_threads = effective_cpus()
-    try:
-        from threadpoolctl import threadpool_limits
-        _limit = threadpool_limits(limits=_cpu_threads)
-    except Exception:
-        _limit = None
-    t0 = time.perf_counter()
-    inf = go.vardtc_inference(kern, X, Z, 0.01, Y)
-    go.sparse_gradients(kern, X, Z, inf)
-    t_eval = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    go.vardtc_inference(kern, X, Z, 0.01, Y)
-    t_lml = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    go.raw_predict(kern, X, Z, inf["woodbury_vector"], inf["woodbury_inv"])
-    go.predictive_gradients_mean(kern, X, Z, inf["woodbury_vector"])
-    t_pred = time.perf_counter() - t0
-    threads = _cpu_threads
-    if _limit is not None:
-        _limit.restore_original_limits()
-    step_time = iters * t_eval + t_lml + t_pred
+    # oversubscribed pool (one thread per visible core of the host) only slows the CPU path down
+    threads = effective_cpus()
+    n1, n2 = sample_rows
+
+    def timed(f):
+        t0 = time.perf_counter()
+        r = f()
+        return time.perf_counter() - t0, r
+
+    def line(t1, t2, m1=None, m2=None):  # t(n) = a + b n through the two samples -> (a, b, t(N))
+        m1, m2 = (n1, n2) if m1 is None else (m1, m2)
+        bb = max((t2 - t1) / (m2 - m1), 0.0)
+        aa = max(t1 - bb * m1, 0.0)
+        return aa, bb, aa + bb * N
+
+    def sample_times(n):
+        Xs, Ys = X[:n], Y[:n]
+        t_b, inf = timed(lambda: go.vardtc_inference(kern, Xs, Z, 0.01, Ys))
+        t_g, _ = timed(lambda: go.sparse_gradients(kern, Xs, Z, inf))
+        t_p, _ = timed(lambda: (go.raw_predict(kern, Xs, Z, inf["woodbury_vector"], inf["woodbury_inv"]),
+                                go.predictive_gradients_mean(kern, Xs, Z, inf["woodbury_vector"])))
+        return t_b, t_b + t_g, t_p
+
+    with threadpool_limits(limits=threads):
+        sample_times(min(n1, 1000))      # untimed: first-call costs (imports, allocator warm-up) stay out of the samples
+        s1, s2 = sample_times(n1), sample_times(n2)
+        t_bound_full, lml_full = None, None
+        if full_bound:
+            t_bound_full, inf = timed(lambda: go.vardtc_inference(kern, X, Z, 0.01, Y))
+            lml_full = float(inf["log_marginal"][0, 0])
+            del inf
+    h1, h2 = n1 // 2, n2 // 2            # the single-thread leg runs on half-size samples
+    with threadpool_limits(limits=1):
+        t1_1, _ = timed(lambda: go.vardtc_inference(kern, X[:h1], Z, 0.01, Y[:h1]))
+        t1_2, _ = timed(lambda: go.vardtc_inference(kern, X[:h2], Z, 0.01, Y[:h2]))
+    _, _, t_bound_model = line(s1[0], s2[0])
+    a_e, b_e, t_eval = line(s1[1], s2[1])
+    _, _, t_pred = line(s1[2], s2[2])
+    _, _, t_bound_1thread = line(t1_1, t1_2, h1, h2)
+    t_bound = t_bound_full if t_bound_full is not None else t_bound_model
+    step_time = iters * t_eval + t_bound + t_pred
     return {
-        "value": N_sample / step_time, "unit": "points/s", "cores": int(threads), "kind": "port",
-        "sample": "%d of the %d rows, M=%d D=%d; one bound+gradient evaluation (%.2f s), one bound (%.2f s) and one "
-                  "predict+predict_gradient pass (%.2f s) timed, step time = %d x eval + bound + predict; "
-                  "log-ml evals/s on the sample: %.3f" % (N_sample, 100000, M, D, t_eval, t_lml, t_pred, iters, 1.0 / t_lml),
-        "lml_evals_per_sec_sample": 1.0 / t_lml,
+        "value": N / step_time, "unit": "points/s", "cores": int(threads), "kind": "port",
+        "sample": "bound: %d of %d rows measured once at full size (%.1f s, %d threads; the two-sample model below predicts "
+                  "%.1f s); bound+gradient evaluation and predict+predict_gradient measured at %d and %d rows (%.2f / %.2f s and "
+                  "%.2f / %.2f s) and extended as a + b N to N = %d (rows-independent part %.2f s, %.3f ms per row): %.1f s and "
+                  "%.1f s; step = %d x eval + bound + predict = %.0f s; M=%d D=%d %s"
+                  % (N if full_bound else 0, N, t_bound, threads, t_bound_model, n1, n2, s1[1], s2[1], s1[2], s2[2], N, a_e,
+                     b_e * 1e3, t_eval, t_pred, iters, step_time, M, D, kind),
+        "lml_evals_per_sec": 1.0 / t_bound,
+        "lml_evals_per_sec_1thread": 1.0 / t_bound_1thread,
+        "bound_full_size_s": t_bound_full, "bound_full_size_value": lml_full,
+        "bound_1thread_s_model": t_bound_1thread,
+        "eval_s_model": t_eval, "predict_s_model": t_pred,
     }
 
 
@@ -155,7 +200,7 @@ def main():
     ap.add_argument("--D", type=int, default=32)
     ap.add_argument("--kind", default="RBF")
     ap.add_argument("--iters", type=int, default=ITERS_PER_FIT)
-    ap.add_argument("--cpu-sample", type=int, default=4000, help="rows of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-baseline", type=int, default=1, help="0 = skip the CPU baseline leg (oracle on the host cores)")
     ap.add_argument("--check-sharding", action="store_true", help="run the sharded-vs-whole check (always on for --gpus > 1)")
     args = ap.parse_args()
 
@@ -190,7 +235,7 @@ def main():
         shard_check = sharding_check(h, dist, rank, world, local_rank)
 
     N, M, D = args.N, args.M, args.D
-    X, y, Z = synthetic(N, D, M, seed=1000 + rank)
+    X, y, Z = synthetic(N, D, M, seed=RANK0_SEED + rank)
     h.set_data(X, y)                           # resident in HBM from here on
     h.set_inducing(Z)
     h.set_kernel([args.kind], [1.0], np.full((1, D), np.sqrt(D)), 0.01)
@@ -225,7 +270,9 @@ def main():
     # log-ml evals/sec (second half of the metric): bound-only evaluations, same resident data
     n_lml = 20
     h.set_kernel([args.kind], [1.0], np.full((1, D), np.sqrt(D)), 0.01)
-    h.sparse_lml()
+    lml_ref_dev = h.sparse_lml()              # (world == 1: same inputs as the CPU leg's full-size bound)
+    if world > 1:
+        lml_ref_dev = None
     barrier_sync()
     t1 = time.perf_counter()
     for _ in range(n_lml):
@@ -292,8 +339,11 @@ def main():
         }
         if shard_check is not None:
             out["sharding_check"] = shard_check
-        if args.cpu_sample > 0 and world == 1:        # rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, M, D, args.kind, args.iters)
+        if args.cpu_baseline and world == 1:          # rank 0 at N=1 only, outside every timed region
+            out["cpu_baseline"] = cpu_baseline(N, M, D, args.kind, args.iters)
+            if lml_ref_dev is not None and out["cpu_baseline"].get("bound_full_size_value") is not None:
+                ref = out["cpu_baseline"]["bound_full_size_value"]
+                out["cpu_baseline"]["device_bound_rel_err"] = abs(lml_ref_dev - ref) / abs(ref)
         print(json.dumps(out))
     if world > 1:
         h.comm_destroy()
