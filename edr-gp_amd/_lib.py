@@ -71,6 +71,7 @@ PROTOTYPES = {
     "edrgp_profile_get": [_ctx_p, ctypes.c_int, _c_double_p, _c_i64_p],
     "edrgp_comm_unique_id": [ctypes.c_void_p],
     "edrgp_comm_init": [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p],
+    "edrgp_comm_init_host": [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p],
     "edrgp_comm_destroy": [_ctx_p],
     "edrgp_dbg_gemm": [_ctx_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                        ctypes.c_double, _c_double_p, ctypes.c_int, _c_double_p, ctypes.c_int,
@@ -86,6 +87,7 @@ PROTOTYPES = {
     "edrgp_dbg_mfma_layout": [_ctx_p, _c_double_p, _c_double_p, _c_double_p],
     "edrgp_calib": [_ctx_p, _c_double_p, _c_double_p],
 }
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, _c_double_p, ctypes.c_int64)
 _RESTYPES = {"edrgp_last_error": ctypes.c_char_p}
 
 _lib = None

@@ -197,8 +197,24 @@ class HipGP:
         buf = ctypes.create_string_buffer(bytes(unique_id), 128)
         check(self._lib.edrgp_comm_init(self._ctx, int(nranks), int(rank), buf))
 
+    def comm_init_host(self, nranks, rank, allreduce):
+        """Row sharding over a collective the launcher provides: ``allreduce(a)`` must sum the float64 numpy
+        array ``a`` over all ranks IN PLACE (e.g. ``dist.all_reduce(torch.from_numpy(a))`` on a gloo group)."""
+        def _cb(_user, buf, count):
+            try:
+                allreduce(np.ctypeslib.as_array(buf, shape=(count,)))
+                return 0
+            except Exception:           # noqa: BLE001  (an exception must not unwind through the C frame)
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._host_ar = _lib.ALLREDUCE_FN(_cb)          # keep the trampoline alive as long as it is attached
+        check(self._lib.edrgp_comm_init_host(self._ctx, int(nranks), int(rank),
+                                             ctypes.cast(self._host_ar, ctypes.c_void_p), None))
+
     def comm_destroy(self):
         check(self._lib.edrgp_comm_destroy(self._ctx))
+        self._host_ar = None
 
     # -- low-level test hooks -----------------------------------------------
     def dbg_gemm(self, A, B, transA=False, transB=False, alpha=1.0, beta=0.0, C=None):

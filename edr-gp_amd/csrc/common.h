@@ -210,12 +210,6 @@ struct Ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;        // side stream: latency-bound O(M^3) work beside the row pass
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // CU-masked stream pair for bound-only evaluations: the side stream owns `side_cus` CUs (spread over the
-    // XCDs), the main stream the rest, so the latency-bound Kmm phase runs beside the row pass at full speed
-    hipStream_t stream_mm = nullptr, stream_ms = nullptr;
-    int side_cus = 0;                     // 0 = off (default: measured gain only 3 %); streams are created on first use
-    int mask_layout = 1;
-    int masked_state = 0;                 // 0 not tried, 1 available, -1 creation failed
     DBuf red2, slabs2;                    // scratch used while launching on the side stream
     DBuf ks_x, ks_z, ks_xn, ks_zn, ks_x2, ks_xn2;   // scaled inputs and squared norms for the MFMA kernel build
     bool mfma_kbuild = true;
@@ -242,6 +236,9 @@ struct Ctx {
     bool fuse_grad = true;            // fused Q .* h epilogue of the gradient contraction (single-part kernels, D <= 32)
     int gemm_dephase = 3;             // see la_gemm.hip: 3 = staging / barrier phases at raised priority
     bool trace = false;
+    bool sync_free = true;            // sparse evaluations wait for the device once, at the end (sparse_eval.hip)
+    int careful_left = 0;             // evaluations that skip the sync-free attempt (after one needed jitter)
+    int64_t retries = 0;              // sync-free attempts repeated by the careful driver
     int num_cu = 256;
 
     // data
@@ -298,6 +295,7 @@ struct Ctx {
     bool knm_train_valid = false;     // c->Knm holds K(X, Z) of ALL training rows for the current theta / Z
     DBuf g2;                          // T^T [X | X.^2] and column sums of T (fused gradient path)
     DBuf slabs, bpart, scal, info, gt_nm, gt_mm, tmpvec[6], panel, trtri_ws, dinv, red, lbaug;
+    DBuf pack;                        // lower triangle of Phi and b, packed for the all-reduce
     std::vector<double> host_scal;
     std::vector<double> Z_host;       // host copy of the inducing inputs (gradient finishing)
     double* h_stage = nullptr;        // pinned staging of the gradient tables
@@ -305,7 +303,12 @@ struct Ctx {
 
     // comm
     void* comm = nullptr;             // ncclComm_t
+    edrgp_allreduce_fn host_ar = nullptr;   // or: the launcher's own sum-all-reduce on host buffers (edrgp_comm_init_host)
+    void* host_ar_user = nullptr;
+    double* h_ar = nullptr;           // pinned staging of that transport
+    size_t h_ar_cap = 0;
     int nranks = 1, rank = 0;
+    bool sharded() const { return comm != nullptr || host_ar != nullptr; }
 
     // profiling
     ProfSlot prof[EDRGP_PROF_NSLOTS];

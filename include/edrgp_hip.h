@@ -63,7 +63,8 @@ typedef struct edrgp_ctx edrgp_ctx;
 #define EDRGP_GET_LBI       11   /* LB^-1                (M x M) */
 #define EDRGP_GET_DLDKMM    12   /* dL/dKmm              (M x M) */
 #define EDRGP_GET_SCALARS   13   /* device scalar slots (16 doubles) */
-#define EDRGP_GET_MODE      14   /* 1: Gram form was used, 2: stable form (buf[0]) */
+#define EDRGP_GET_MODE      14   /* buf[0]: 1 Gram form was used, 2 stable form, 3 fp32 Gram; [1] fp32 guard estimate; [2] (max/min diag Lm)^2;
+                                    [3] number of sync-free evaluations repeated by the careful driver */
 
 /* profile slots: device time of kernel families measured with HIP events on
  * the context's stream (bench.py roofline) */
@@ -98,7 +99,12 @@ int  edrgp_sync(edrgp_ctx* ctx);
  * "posterior_reuse" (edrgp_sparse_posterior right after a bound+gradient evaluation of the same state is
  *  served from that evaluation's factors),
  * "mfma_kbuild", "kbuild_tile" (64 / 128),
- * "gemm_dephase", "tri_tile"; "side_cus" (CU-masked stream pair for bound-only evaluations, default 0 = off);
+ * "gemm_dephase", "tri_tile";
+ * "sync_free" (default 1): a sparse evaluation queues all its phases for the statistics form the previous one ended in
+ *  and waits for the device once, at the end, where it also reads the device's verdict (Cholesky info words,
+ *  pivot-ratio proxy); if the verdict disagrees -- jitter needed, or the other form -- the evaluation is repeated with
+ *  a synchronisation after each factorisation (0 = always that way).  Results are those of the form the
+ *  pivot-ratio rule selects for the current Kmm either way;
  * "trace" (host-side phase timing to stderr). */
 int  edrgp_set_option(edrgp_ctx* ctx, const char* key, double value);
 
@@ -169,10 +175,17 @@ int  edrgp_profile_get(edrgp_ctx* ctx, int slot, double* total_ms, int64_t* laun
 
 /* Row-sharded multi-GPU (one process per GPU): all ranks hold the same Z and
  * hyper-parameters and a row block of (X, y); Phi, K_mn y and the scalars are
- * sum-all-reduced over RCCL once per evaluation (GPy's own unused precedent:
- * VarDTC_minibatch + mpi4py Allreduce). */
+ * sum-all-reduced over RCCL once per evaluation -- the lower triangle of Phi and b, M (M + 1) / 2 + M doubles --
+ * (GPy's own unused precedent: VarDTC_minibatch + mpi4py Allreduce).  Every rank must make the same sequence of
+ * calls; the number and content of the collectives never depend on a rank's local row count. */
 int  edrgp_comm_unique_id(void* id128);                 /* 128-byte ncclUniqueId */
 int  edrgp_comm_init(edrgp_ctx* ctx, int nranks, int rank, const void* id128);
+/* The same sharding over a collective the LAUNCHER provides (MPI, gloo, torch.distributed ...): `fn` must sum
+ * `count` doubles in `buf` (host memory) over all ranks in place and return 0.  The library stages the exchanged
+ * statistics through pinned host memory.  Slower than RCCL over xGMI; meant for hosts without a usable RCCL fabric
+ * and for exercising the sharded control flow with several processes on one device. */
+typedef int (*edrgp_allreduce_fn)(void* user, double* buf, int64_t count);
+int  edrgp_comm_init_host(edrgp_ctx* ctx, int nranks, int rank, edrgp_allreduce_fn fn, void* user);
 int  edrgp_comm_destroy(edrgp_ctx* ctx);
 
 /* Low-level device linear algebra on host buffers -- test hooks for the
