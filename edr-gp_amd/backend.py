@@ -253,6 +253,13 @@ class HipGP:
         check(self._lib.edrgp_dbg_potrf(self._ctx, dptr(L), L.shape[0], ctypes.byref(info)))
         return L, info.value
 
+    def dbg_potrf_inv(self, A):
+        L = as_f64(A).copy()
+        Li = np.empty_like(L)
+        info = ctypes.c_int(0)
+        check(self._lib.edrgp_dbg_potrf_inv(self._ctx, dptr(L), L.shape[0], ctypes.byref(info), dptr(Li)))
+        return L, Li, info.value
+
     def dbg_trtri(self, L):
         L = as_f64(L)
         out = np.empty_like(L)

@@ -115,8 +115,7 @@ static int dense_eval(Ctx* c, bool need_grad, bool need_post, DenseOut* out) {
         HIP_TRY(hipMemsetAsync(sc, 0, SC_COUNT * sizeof(double), c->stream));
         TRY(kernel_matrix(c, ks, c->X.d(), n, c->X.d(), n, L, n, 1,
                           c->noise_var + 1e-8 + jit_amount(lvl, diag_mean_), nullptr, nullptr));
-        TRY(potrf_lower(c, L, n, n, info));
-        TRY(trtri_lower(c, L, n, Li, n, n));
+        TRY(potrf_inv_lower(c, L, n, n, info, Li, n));
         TRY(gram_of_lower(c, n, Li, Kyi));
         TRY(gemv_n(c, n, n, 1.0, Kyi, n, c->y.d(), alpha));
         TRY(sum_log_diag(c, L, n, n, sc + SC_SUMLOGL));
@@ -351,6 +350,7 @@ int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
     else if (!std::strcmp(key, "kbuild_tile")) c->kbuild_tile = (int)value;
     else if (!std::strcmp(key, "rbf_epilogue")) c->rbf_epilogue = (value != 0.0);
     else if (!std::strcmp(key, "chol_fused")) c->chol_fused = (value != 0.0);
+    else if (!std::strcmp(key, "chol_inv_fused")) c->chol_inv_fused = (value != 0.0);
     else if (!std::strcmp(key, "chol_rhs")) c->chol_rhs = (value != 0.0);
     else if (!std::strcmp(key, "pad_inducing")) c->pad_inducing = (value != 0.0);
     else if (!std::strcmp(key, "gemm_pair")) c->gemm_pair = (value != 0.0);
@@ -749,6 +749,26 @@ int edrgp_dbg_potrf(edrgp_ctx* ctx, double* A, int n, int* info) {
     }
     dA.release();
     return s;
+}
+
+// Cholesky factor and its inverse out of the same launches (la_chol.hip::potrf_inv_lower)
+int edrgp_dbg_potrf_inv(edrgp_ctx* ctx, double* A, int n, int* info, double* Linv) {
+    CTX(ctx);
+    if (!A || !Linv || n <= 0) { set_error("dbg_potrf_inv: bad input"); return EDRGP_ERR_INVALID; }
+    DBuf dA, dI;
+    TRY(dA.reserve((size_t)n * n * sizeof(double)));
+    TRY(dI.reserve((size_t)n * n * sizeof(double)));
+    TRY(c->info.reserve(4 * sizeof(int)));
+    HIP_TRY(hipMemcpy(dA.d(), A, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(dI.d(), 0xff, (size_t)n * n * sizeof(double)));          // NaN pattern: every entry must be written
+    TRY(potrf_inv_lower(c, dA.d(), n, n, static_cast<int*>(c->info.p), dI.d(), n));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(A, dA.d(), (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(Linv, dI.d(), (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost));
+    int h = 0;
+    HIP_TRY(hipMemcpy(&h, c->info.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (info) *info = h;
+    return EDRGP_OK;
 }
 
 // diagnostic: phase stamps (shader cycles) of one diagonal-block kernel launch

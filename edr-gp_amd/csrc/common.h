@@ -144,6 +144,8 @@ int fill_pattern(Ctx* c, double* K, size_t n, unsigned long long seed);   // dev
 int potrf_lower(Ctx* c, double* A, int n, int lda, int* info_dev);
 // Linv = L^-1 for lower-triangular L (explicit zeros above the diagonal of the output).
 int trtri_lower(Ctx* c, const double* L, int ldl, double* Linv, int ldi, int n);
+// both at once (one launch per 64-column step for n in (64, 3072]: la_chol.hip)
+int potrf_inv_lower(Ctx* c, double* A, int n, int lda, int* info_dev, double* Linv, int ldi);
 int diag_block_stamps(Ctx* c, double* A64, double* Dinv64, unsigned long long* stamps_dev, int do_chol);
 
 // -------------------------------------------------------------- vector helpers
@@ -232,6 +234,7 @@ struct Ctx {
     int M_work = 0;                   // working size of the last sparse evaluation (>= M)
     bool chol_rhs = true;             // bound-only evaluations: L_B^-1 (beta v) as an extra row of the factorisation, no explicit L_B^-1
     bool chol_fused = true;           // Cholesky: panel + trailing update in one launch per step (la_chol.hip)
+    bool chol_inv_fused = true;       // ... and the inverse of the factor out of the same launches
     bool rbf_epilogue = true;         // RBF: fused gradient epilogue takes h(r) = -k(r) from the resident K_nm
     bool fuse_grad = true;            // fused Q .* h epilogue of the gradient contraction (single-part kernels, D <= 32)
     int gemm_dephase = 3;             // see la_gemm.hip: 3 = staging / barrier phases at raised priority

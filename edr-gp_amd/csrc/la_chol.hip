@@ -315,10 +315,22 @@ __global__ void fill_kernel(double* __restrict__ A, size_t count, double v) {
 // read, so there is no ordering between workgroups.  256 threads = 2x2 waves, a wave owns a 32x32 quadrant.
 // LDS: the two operand tiles as [row][k] images (stride 66: conflict-free ds_read_b64 per half-wave), reused
 // for L_ik / L_jk; the Dinv fragments (same for both products) sit in registers.
+//
+// The inverse rides along (Cw != nullptr): the identity is appended below A as block rows C_0 .. C_{T-1} and goes
+// through the same panel + trailing steps, which turn it into L^-T (forward substitution of the identity by the
+// updates that run anyway, as the right-hand side row of bound-only evaluations does):
+//     C_ik <- C_ik Dinv^T          (i <= k: C is upper triangular)       = final block (i, k) of L^-T
+//     C_ij -= C_ik L_jk^T          (j > k)
+// Workgroups [ntri, ntri + (k + 1) r) take these tiles (block row ci of C, trailing column tj); those of the first
+// trailing column store the finished block TRANSPOSED into Linv (block (k, ci) of L^-1).  Block row k of C is still
+// the identity when step k reads it and no tile of C is read before step `row` has written it, so C needs no
+// initialisation.  A last launch (panel_only) finishes block column T - 1.  This replaces the recursive-doubling
+// triangular inverse (12 launches, 0.34 ms at n = 2048) at no additional launch.
 __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ A, int lda, double* __restrict__ Lout,
                                                            int ldl, const double* __restrict__ Dinv, int n, int k,
                                                            double* __restrict__ Dinv_next, int* __restrict__ info,
-                                                           int info_off) {
+                                                           int info_off, int ntri, double* __restrict__ Cw, int ldc,
+                                                           double* __restrict__ Linv, int ldi, int panel_only) {
     constexpr int LS = NB + 2;
     static_assert(2 * NB * LS >= DIAG_LDS, "the diagonal-block body reuses the operand tiles' LDS");
     __shared__ __attribute__((aligned(16))) double Rbuf[2 * NB * LS];
@@ -326,16 +338,28 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ 
     double* R2 = Rbuf + NB * LS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lq = lane >> 4;
+    const bool inv_tile = ((int)blockIdx.x >= ntri);
     int ti, tj;
-    {
+    if (!inv_tile) {
         const int t = blockIdx.x;
         ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
         while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
         while (ti * (ti + 1) / 2 > t) --ti;
         tj = t - ti * (ti + 1) / 2;
+    } else {
+        const int u = (int)blockIdx.x - ntri;
+        ti = u % (k + 1);                // block row of C
+        tj = u / (k + 1);                // trailing column (0 when panel_only)
     }
-    const int i0 = (k + 1 + ti) * NB, j0 = (k + 1 + tj) * NB, k0 = k * NB;
-    const bool diag = (ti == tj);
+    const int k0 = k * NB;
+    const int i0 = inv_tile ? ti * NB : (k + 1 + ti) * NB;
+    const int j0 = (k + 1 + tj) * NB;
+    const bool diag = !inv_tile && (ti == tj);
+    const bool ident = inv_tile && (ti == k);          // block row k of C: still the identity, its tiles right of k zero
+    // the "i" panel tile and the tile being updated live in A (Cholesky tiles) or in C (inverse tiles)
+    const double* Pi = inv_tile ? Cw : A;
+    double* Ct = inv_tile ? Cw : A;
+    const int ldp = inv_tile ? ldc : lda;
 
     // Dinv fragments: b[st][y] = B[q = 4 st + lq][c = 32 wn + 16 y + lr] = Dinv[c][q]
     double db[16][2];
@@ -353,21 +377,27 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = i0 + 32 * wm + 16 * x + lq + 4 * r, col = j0 + 32 * wn + 16 * y + lr;
-                Cij[x][y][r] = (row < n && col < n) ? A[(size_t)row * lda + col] : 0.0;
+                Cij[x][y][r] = (!panel_only && !ident && row < n && col < n) ? Ct[(size_t)row * ldp + col] : 0.0;
             }
-    // stage A_ik and A_jk: thread -> rows tid/32 + 8 v, columns 2 (tid % 32), 16-byte loads
+    // stage the two panel tiles: thread -> rows tid/32 + 8 v, columns 2 (tid % 32), 16-byte loads
     {
         const int c2 = (tid & 31) * 2, r8 = tid >> 5;
         const bool al = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((lda & 1) == 0);
+        const bool alp = ((reinterpret_cast<uintptr_t>(Pi) & 15) == 0) && ((ldp & 1) == 0);
 #pragma unroll
         for (int v = 0; v < 8; ++v) {
             const int r = r8 + 8 * v;
             double2 a1 = {0.0, 0.0}, a2 = {0.0, 0.0};
-            if (i0 + r < n) {
-                const double* p = A + (size_t)(i0 + r) * lda + k0 + c2;
-                if (al) a1 = *reinterpret_cast<const double2*>(p); else { a1.x = p[0]; a1.y = p[1]; }
+            if (ident) {
+                a1.x = (r == c2) ? 1.0 : 0.0;
+                a1.y = (r == c2 + 1) ? 1.0 : 0.0;
+            } else if (i0 + r < n) {
+                // (the panel columns are whole except in the panel-only launch, whose block column may be ragged)
+                const double* p = Pi + (size_t)(i0 + r) * ldp + k0 + c2;
+                if (alp && k0 + c2 + 1 < n) a1 = *reinterpret_cast<const double2*>(p);
+                else { a1.x = (k0 + c2 < n) ? p[0] : 0.0; a1.y = (k0 + c2 + 1 < n) ? p[1] : 0.0; }
             }
-            if (!diag && j0 + r < n) {
+            if (!diag && !panel_only && j0 + r < n) {
                 const double* p = A + (size_t)(j0 + r) * lda + k0 + c2;
                 if (al) a2 = *reinterpret_cast<const double2*>(p); else { a2.x = p[0]; a2.y = p[1]; }
             }
@@ -382,23 +412,24 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ 
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y) { Li[x][y] = d4{0.0, 0.0, 0.0, 0.0}; Lj[x][y] = d4{0.0, 0.0, 0.0, 0.0}; }
+    const bool two = !diag && !panel_only;
 #pragma unroll
     for (int st = 0; st < 16; ++st) {
         double a1[2], a2[2];
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
             a1[x] = R1[(32 * wm + 16 * x + lr) * LS + 4 * st + lq];
-            a2[x] = diag ? 0.0 : R2[(32 * wm + 16 * x + lr) * LS + 4 * st + lq];
+            a2[x] = two ? R2[(32 * wm + 16 * x + lr) * LS + 4 * st + lq] : 0.0;
         }
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
             for (int y = 0; y < 2; ++y) {
                 Li[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[x], db[st][y], Li[x][y], 0, 0, 0);
-                if (!diag) Lj[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[x], db[st][y], Lj[x][y], 0, 0, 0);
+                if (two) Lj[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[x], db[st][y], Lj[x][y], 0, 0, 0);
             }
     }
-    __syncthreads();                     // everyone has read the A tiles: overwrite them with L_ik / L_jk
+    __syncthreads();                     // everyone has read the panel tiles: overwrite them with L_ik / L_jk
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -407,10 +438,21 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ 
             for (int r = 0; r < 4; ++r) {
                 const int row = 32 * wm + 16 * x + lq + 4 * r, col = 32 * wn + 16 * y + lr;
                 R1[row * LS + col] = Li[x][y][r];
-                if (!diag) R2[row * LS + col] = Lj[x][y][r];
-                if (tj == 0 && i0 + row < n) Lout[(size_t)(i0 + row) * ldl + k0 + col] = Li[x][y][r];
+                if (two) R2[row * LS + col] = Lj[x][y][r];
+                if (!inv_tile && tj == 0 && i0 + row < n) Lout[(size_t)(i0 + row) * ldl + k0 + col] = Li[x][y][r];
             }
     __syncthreads();
+    if (inv_tile && tj == 0) {
+        // finished block (ci, k) of L^-T -> block (k, ci) of L^-1, transposed through LDS: consecutive lanes write
+        // consecutive columns of one row of Linv
+        const int cc = tid & 63;                     // column of Linv within the block = row of the C tile
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int rr = (tid >> 6) + 4 * v;         // row of Linv within the block = column of the C tile
+            if (k0 + rr < n && i0 + cc < n) Linv[(size_t)(k0 + rr) * ldi + i0 + cc] = R1[cc * LS + rr];
+        }
+    }
+    if (panel_only) return;
 
     const double* Rj = diag ? R1 : R2;
     d4 S[2][2];
@@ -438,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = i0 + 32 * wm + 16 * x + lq + 4 * r, col = j0 + 32 * wn + 16 * y + lr;
-                if (row < n && col < n) A[(size_t)row * lda + col] = Cij[x][y][r] - S[x][y][r];
+                if (row < n && col < n) Ct[(size_t)row * ldp + col] = Cij[x][y][r] - S[x][y][r];
             }
     // The workgroup of tile (k+1, k+1) has just produced the next diagonal block: factor and invert it here,
     // so the next step needs no separate (cold, 16 us) diagonal-block launch on the critical path.
@@ -456,9 +498,10 @@ __global__ void take_lower_kernel(double* __restrict__ A, int lda, const double*
 }
 
 // Fused-step variant of potrf_lower (same contract): the factor is assembled in the panel workspace and
-// copied back, A is the work matrix of the trailing updates.
+// copied back, A is the work matrix of the trailing updates.  With Linv != nullptr the inverse L^-1 comes out of
+// the same launches (see chol_step_kernel).
 static int potrf_lower_fused(Ctx* c, double* A, int n, int lda, int* info_dev, bool reset_info = true,
-                             int info_off = 0) {
+                             int info_off = 0, double* Linv = nullptr, int ldi = 0) {
     if (reset_info) HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), c->stream));
     if (c->dinv.bytes < (size_t)2 * NB * NB * sizeof(double)) {
         TRY(c->dinv.reserve((size_t)2 * NB * NB * sizeof(double)));
@@ -468,20 +511,46 @@ static int potrf_lower_fused(Ctx* c, double* A, int n, int lda, int* info_dev, b
     TRY(c->panel.reserve((size_t)n * n * sizeof(double)));
     double* Dinv = c->dinv.d();                       // two slabs: step b reads [b & 1] and writes [(b + 1) & 1]
     double* Lw = c->panel.d();
+    double* Cw = nullptr;
+    if (Linv != nullptr) {
+        TRY(c->trtri_ws.reserve((size_t)n * n * sizeof(double)));
+        Cw = c->trtri_ws.d();                         // the appended identity rows (never initialised: see the kernel)
+        if (ldi == n) {
+            hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, c->stream, Linv, (size_t)n * n, 0.0);
+        } else {
+            HIP_TRY(hipMemset2DAsync(Linv, (size_t)ldi * sizeof(double), 0, (size_t)n * sizeof(double), (size_t)n, c->stream));
+        }
+    }
     const int nblk = (n + NB - 1) / NB;
     hipLaunchKernelGGL(diag_block_kernel<true>, dim3(1), dim3(256), 0, c->stream, A, lda, n, 0, Dinv, (double*)nullptr, 0,
                        info_dev, (unsigned long long*)nullptr, Lw, n, info_off);
     for (int b = 0; b + 1 < nblk; ++b) {
         const int r = nblk - b - 1;
-        // one launch per step: panel + trailing update of every tile, and the factor + inverse of the next
-        // diagonal block by the workgroup that has just finished it
-        hipLaunchKernelGGL(chol_step_kernel, dim3((unsigned)(r * (r + 1) / 2)), dim3(256), 0, c->stream, A, lda, Lw, n,
-                           Dinv + (size_t)(b & 1) * NB * NB, n, b, Dinv + (size_t)((b + 1) & 1) * NB * NB, info_dev, info_off);
+        const int ntri = r * (r + 1) / 2;
+        const int ninv = (Cw != nullptr) ? (b + 1) * r : 0;
+        // one launch per step: panel + trailing update of every tile (of A and of the appended identity rows), and
+        // the factor + inverse of the next diagonal block by the workgroup that has just finished it
+        hipLaunchKernelGGL(chol_step_kernel, dim3((unsigned)(ntri + ninv)), dim3(256), 0, c->stream, A, lda, Lw, n,
+                           Dinv + (size_t)(b & 1) * NB * NB, n, b, Dinv + (size_t)((b + 1) & 1) * NB * NB, info_dev, info_off,
+                           ntri, Cw, n, Linv, ldi, 0);
     }
+    if (Cw != nullptr)                                // block column nblk - 1 of L^-T: panel products only
+        hipLaunchKernelGGL(chol_step_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, A, lda, Lw, n,
+                           Dinv + (size_t)((nblk - 1) & 1) * NB * NB, n, nblk - 1, (double*)nullptr, info_dev, info_off, 0, Cw,
+                           n, Linv, ldi, 1);
     dim3 blk(64, 4), grd((n + 63) / 64, (n + 3) / 4);
     hipLaunchKernelGGL(take_lower_kernel, grd, blk, 0, c->stream, A, lda, Lw, n, n);
     HIP_TRY(hipGetLastError());
     return EDRGP_OK;
+}
+
+// Cholesky factor and its inverse: A <- L (lower, zeros above), Linv <- L^-1.  n in (64, 3072]: out of the same
+// launches; otherwise factorisation, then the recursive-doubling inverse.
+int potrf_inv_lower(Ctx* c, double* A, int n, int lda, int* info_dev, double* Linv, int ldi) {
+    if (c->chol_fused && c->chol_inv_fused && n > NB && n <= 3072)
+        return potrf_lower_fused(c, A, n, lda, info_dev, true, 0, Linv, ldi);
+    TRY(potrf_lower(c, A, n, lda, info_dev));
+    return trtri_lower(c, A, lda, Linv, ldi, n);
 }
 
 int potrf_lower(Ctx* c, double* A, int n, int lda, int* info_dev) {

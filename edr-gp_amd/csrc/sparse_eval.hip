@@ -196,9 +196,8 @@ struct SparseEval {
         TRY(kernel_matrix(c, ks, c->Z.d(), Mr, c->Z.d(), Mr, Lm, M, 1, 1e-8 + jit_amount(lvl, kmm_diag_mean), nullptr,
                           nullptr));
         if (padded) TRY(add_diag(c, Lm + (size_t)Mr * M + Mr, M - Mr, M, 1.0));
-        TRY(potrf_lower(c, Lm, M, M, info + 0));
+        TRY(potrf_inv_lower(c, Lm, M, M, info + 0, Li, M));
         TRY(diag_minmax(c, Lm, Mr, M, sc + SC_DIAGMIN));
-        TRY(trtri_lower(c, Lm, M, Li, M, M));
         return EDRGP_OK;
     }
     // careful driver: GPy's jitchol ladder, one synchronisation per attempt
@@ -340,8 +339,7 @@ struct SparseEval {
         HIP_TRY(hipMemcpyAsync(LB, A, (size_t)M * M * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         // jitter on B: mean(diag(B)) = 1 + trA / M, trA known from the failed pass
         TRY(add_diag(c, LB, M, M, bjit));
-        TRY(potrf_lower(c, LB, M, M, info + 1));
-        TRY(trtri_lower(c, LB, M, LBi, M, M));
+        TRY(potrf_inv_lower(c, LB, M, M, info + 1, LBi, M));
         TRY(sum_log_diag(c, LB, M, M, sc + SC_SUMLOGLB));
         // c = beta LBi v ; u = LBi^T c ; wv = Li^T u     (v = Lm^-1 K_mn y)
         TRY(gemv_n(c, M, M, beta, LBi, M, v_v, v_c));

@@ -98,6 +98,29 @@ def test_potrf_large(hip, n):
     assert info == 3091
 
 
+@pytest.mark.parametrize("n", [1, 64, 65, 100, 128, 129, 200, 257, 512, 1000, 2048, 2049, 3072, 3100])
+def test_potrf_with_inverse(hip, n):
+    """Factor and inverse of the factor out of the same launches (n in (64, 3072]: the appended identity rows ride
+    through the fused steps; outside: factorisation + recursive-doubling inverse).  The factor must be bit-identical
+    to the factorisation alone; every entry of the inverse is written (the output buffer starts as NaN)."""
+    A = _spd(n, n, cond=1e3)
+    L, Li, info = hip.dbg_potrf_inv(A)
+    assert info == 0
+    L0, _ = hip.dbg_potrf(A)
+    assert np.array_equal(L, L0)
+    assert np.all(np.isfinite(Li))
+    assert np.array_equal(np.triu(Li, 1), np.zeros_like(Li))
+    ref = sla.solve_triangular(np.linalg.cholesky(A), np.eye(n), lower=True)
+    assert rel(Li, ref) < 1e-10
+    assert rel(Li @ L, np.eye(n)) < 1e-11
+    hip.set_option("chol_inv_fused", 0)
+    try:
+        _, Li2, _ = hip.dbg_potrf_inv(A)
+    finally:
+        hip.set_option("chol_inv_fused", 1)
+    assert rel(Li, Li2) < 1e-11
+
+
 def test_potrf_reports_failure(hip):
     A = _spd(130, 3)
     A[100, 100] = -1.0
