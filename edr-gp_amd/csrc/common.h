@@ -113,6 +113,7 @@ struct GemmOpts {
     int kmode = 0;                           // zero-skipping for triangular operands, see K_* below
     int force_tile = 0;                      // 64 or 128; 0 = heuristic; -1 = 128 if that gives >= 1024 tiles, else small_tile
     int small_tile = 64;
+    int dyn_lds = 0;                         // tag 3 only: extra LDS bytes per workgroup (occupancy control, see sparse_eval.hip)
 };
 
 // k-range restrictions (GemmOpts::kmode) for triangular operands
@@ -217,6 +218,8 @@ struct Ctx {
     bool mfma_kbuild = true;
     int kbuild_dbg = 0;
     int kbuild_tile = 64;                // tile of the MFMA kernel build (64 or 128)
+    int kbuild_pad = 16384;              // LDS padding of the K_nm build while phase 1 runs beside it (bytes; 0 = none)
+    int kbuild_pad_now = 0;              // padding in force for the next build launch
     int overlap = 3;                  // 0 none; 1 Kmm gradient term beside the gradient contraction;
                                       // 2 also phase 1 beside the row pass (stretches the Phi kernel);
                                       // 3 = 2 for bound-only evaluations, 1 for gradient evaluations

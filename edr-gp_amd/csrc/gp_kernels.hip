@@ -279,6 +279,7 @@ static int kernel_matrix_mfma(Ctx* c, const KSpec& ks, const double* X, int64_t 
     o.tag = 3;
     o.force_tile = tile;
     o.fusek = &f;
+    o.dyn_lds = (tile == 64) ? c->kbuild_pad_now : 0;
     TRY(gemm(c, false, true, (int)rows, M2, D, 1.0, c->ks_x.d(), D, Zs, D, 0.0, K, ldk, o));
     if (y != nullptr) TRY(col_reduce(c, c->bpart.d(), tiles_m, M2, bvec));
     return EDRGP_OK;

@@ -39,12 +39,14 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // and report the first non-positive pivot; then (both modes) invert it.  Outputs:
 // the inverse into Dinv (dense 64x64, ld 64, blockIdx-th slab; upper blocks are
 // never written and must be zero) and/or into inv_out (ld ldi, jb x jb part).
-// LDS footprint of the body, in doubles: Lt[64][65] | Tl[4][16][17] | rdiag[64] | Pn[64][17]
-constexpr int DIAG_LDS = NB * (NB + 1) + 4 * 16 * 17 + NB + NB * 17;
+// LDS footprint of the body, in doubles: Lt[64][65] | Tl[4][16][17] = Pn[64][17] (the panel image is dead when the
+// inverse starts) | rdiag[64]: 42.5 KB, so that a workgroup carrying it fits into the LDS one retiring workgroup of
+// the K_nm build leaves free on a CU (160 KB - 3 x 36.9 KB) -- see chol_step_kernel
+constexpr int DIAG_LDS = NB * (NB + 1) + 4 * 16 * 17 + NB;
 
 // The body is a device function so that the fused Cholesky step kernel can run it on the workgroup that has
 // just finished the next diagonal tile (256 threads, `lds` = DIAG_LDS doubles, uniform call per workgroup).
-template <bool DO_CHOL>
+template <bool DO_CHOL, bool PRELOADED = false>
 __device__ __forceinline__ void diag_block_body(double* __restrict__ Abase, int lda, int n, int blk,
                                                 double* __restrict__ Dinv_slab, double* __restrict__ inv_out, int ldi,
                                                 int* __restrict__ info, unsigned long long* __restrict__ stamps,
@@ -53,7 +55,7 @@ __device__ __forceinline__ void diag_block_body(double* __restrict__ Abase, int 
     double (*Lt)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(lds);                       // Lt[k][i] = L[i][k]
     double (*Tl)[16][17] = reinterpret_cast<double (*)[16][17]>(lds + NB * (NB + 1));       // inverses of the 16x16 diagonal blocks
     double* rdiag = lds + NB * (NB + 1) + 4 * 16 * 17;                                      // 1 / L[i][i]
-    double (*Pn)[17] = reinterpret_cast<double (*)[17]>(lds + NB * (NB + 1) + 4 * 16 * 17 + NB);   // current 16-column panel
+    double (*Pn)[17] = reinterpret_cast<double (*)[17]>(lds + NB * (NB + 1));               // current 16-column panel (aliases Tl)
 #define EDRGP_STAMP(slot) do { if (stamps != nullptr && threadIdx.x == 0) stamps[slot] = __builtin_amdgcn_s_memtime(); } while (0)
     EDRGP_STAMP(0);
     // 4 waves: all of them move data (load, write-back, the four column chains of the inverse); the
@@ -63,7 +65,7 @@ __device__ __forceinline__ void diag_block_body(double* __restrict__ Abase, int 
     const int j0 = blk * NB;
     const int jb = min(NB, n - j0);
     double* A = Abase + (size_t)j0 * lda + j0;
-    {
+    if (!PRELOADED) {                               // PRELOADED: the caller has filled Lt (identity padded) and synchronised
         const int cl = min(lane, jb - 1);
         const int r0 = 16 * wave;                   // coalesced, clamped (branch-free), 16 rows in flight per wave
         double t[16];
@@ -75,8 +77,8 @@ __device__ __forceinline__ void diag_block_body(double* __restrict__ Abase, int 
             const bool in = (r < jb) && (lane < jb) && (lane <= r);
             Lt[lane][r] = in ? t[u] : ((r == lane) ? 1.0 : 0.0);
         }
+        __syncthreads();
     }
-    __syncthreads();
     EDRGP_STAMP(1);
 
     if (DO_CHOL) {
@@ -326,16 +328,20 @@ __global__ void fill_kernel(double* __restrict__ A, size_t count, double v) {
 // the identity when step k reads it and no tile of C is read before step `row` has written it, so C needs no
 // initialisation.  A last launch (panel_only) finishes block column T - 1.  This replaces the recursive-doubling
 // triangular inverse (12 launches, 0.34 ms at n = 2048) at no additional launch.
+// LDS: ONE 64x66 tile image, refilled as the step proceeds, plus the diagonal-block body's extra 8.7 KB: 42.5 KB.
+// That is less than what one retiring workgroup of the K_nm build frees on a CU that holds four of them, so the
+// steps of the Kmm factorisation (high-priority side stream) get workgroup slots while the build streams beside them;
+// with two tile images (67.6 KB) a step waited for two build workgroups of one CU to retire together, and the first
+// two steps of phase 1 took 494 + 164 us instead of 2 x 38.
 __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ A, int lda, double* __restrict__ Lout,
                                                            int ldl, const double* __restrict__ Dinv, int n, int k,
                                                            double* __restrict__ Dinv_next, int* __restrict__ info,
                                                            int info_off, int ntri, double* __restrict__ Cw, int ldc,
                                                            double* __restrict__ Linv, int ldi, int panel_only) {
     constexpr int LS = NB + 2;
-    static_assert(2 * NB * LS >= DIAG_LDS, "the diagonal-block body reuses the operand tiles' LDS");
-    __shared__ __attribute__((aligned(16))) double Rbuf[2 * NB * LS];
-    double* R1 = Rbuf;
-    double* R2 = Rbuf + NB * LS;
+    constexpr int LDS_DOUBLES = (NB * LS > DIAG_LDS) ? NB * LS : DIAG_LDS;
+    __shared__ __attribute__((aligned(16))) double Rbuf[LDS_DOUBLES];
+    double* R = Rbuf;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lq = lane >> 4;
     const bool inv_tile = ((int)blockIdx.x >= ntri);
@@ -356,6 +362,7 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ 
     const int j0 = (k + 1 + tj) * NB;
     const bool diag = !inv_tile && (ti == tj);
     const bool ident = inv_tile && (ti == k);          // block row k of C: still the identity, its tiles right of k zero
+    const bool two = !diag && !panel_only;             // a second panel tile (row block j of A) takes part
     // the "i" panel tile and the tile being updated live in A (Cholesky tiles) or in C (inverse tiles)
     const double* Pi = inv_tile ? Cw : A;
     double* Ct = inv_tile ? Cw : A;
@@ -368,7 +375,8 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ 
 #pragma unroll
         for (int y = 0; y < 2; ++y) db[st][y] = Dinv[(32 * wn + 16 * y + lr) * NB + 4 * st + lq];
 
-    // the tile being updated: loaded now, used in the epilogue (no exposed global latency there)
+    // every global operand is requested up front: the tile being updated (used in the epilogue) and both panel
+    // tiles (thread -> rows tid/32 + 8 v, columns 2 (tid % 32), 16-byte loads); the second one waits in registers
     d4 Cij[2][2];
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -379,15 +387,16 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ 
                 const int row = i0 + 32 * wm + 16 * x + lq + 4 * r, col = j0 + 32 * wn + 16 * y + lr;
                 Cij[x][y][r] = (!panel_only && !ident && row < n && col < n) ? Ct[(size_t)row * ldp + col] : 0.0;
             }
-    // stage the two panel tiles: thread -> rows tid/32 + 8 v, columns 2 (tid % 32), 16-byte loads
+    const int c2 = (tid & 31) * 2, r8 = tid >> 5;
+    double2 a2v[8];
     {
-        const int c2 = (tid & 31) * 2, r8 = tid >> 5;
         const bool al = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((lda & 1) == 0);
         const bool alp = ((reinterpret_cast<uintptr_t>(Pi) & 15) == 0) && ((ldp & 1) == 0);
 #pragma unroll
         for (int v = 0; v < 8; ++v) {
             const int r = r8 + 8 * v;
-            double2 a1 = {0.0, 0.0}, a2 = {0.0, 0.0};
+            double2 a1 = {0.0, 0.0};
+            a2v[v] = double2{0.0, 0.0};
             if (ident) {
                 a1.x = (r == c2) ? 1.0 : 0.0;
                 a1.y = (r == c2 + 1) ? 1.0 : 0.0;
@@ -397,39 +406,49 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ 
                 if (alp && k0 + c2 + 1 < n) a1 = *reinterpret_cast<const double2*>(p);
                 else { a1.x = (k0 + c2 < n) ? p[0] : 0.0; a1.y = (k0 + c2 + 1 < n) ? p[1] : 0.0; }
             }
-            if (!diag && !panel_only && j0 + r < n) {
+            if (two && j0 + r < n) {
                 const double* p = A + (size_t)(j0 + r) * lda + k0 + c2;
-                if (al) a2 = *reinterpret_cast<const double2*>(p); else { a2.x = p[0]; a2.y = p[1]; }
+                if (al) a2v[v] = *reinterpret_cast<const double2*>(p); else { a2v[v].x = p[0]; a2v[v].y = p[1]; }
             }
-            *reinterpret_cast<double2*>(&R1[r * LS + c2]) = a1;
-            if (!diag) *reinterpret_cast<double2*>(&R2[r * LS + c2]) = a2;
+            *reinterpret_cast<double2*>(&R[r * LS + c2]) = a1;
         }
     }
     __syncthreads();
 
+    // panel products on the matrix pipe: L_i = (tile i) Dinv^T, then L_j likewise through the same LDS image
     d4 Li[2][2], Lj[2][2];
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y) { Li[x][y] = d4{0.0, 0.0, 0.0, 0.0}; Lj[x][y] = d4{0.0, 0.0, 0.0, 0.0}; }
-    const bool two = !diag && !panel_only;
 #pragma unroll
     for (int st = 0; st < 16; ++st) {
-        double a1[2], a2[2];
+        double a1[2];
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            a1[x] = R1[(32 * wm + 16 * x + lr) * LS + 4 * st + lq];
-            a2[x] = two ? R2[(32 * wm + 16 * x + lr) * LS + 4 * st + lq] : 0.0;
-        }
+        for (int x = 0; x < 2; ++x) a1[x] = R[(32 * wm + 16 * x + lr) * LS + 4 * st + lq];
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
-            for (int y = 0; y < 2; ++y) {
-                Li[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[x], db[st][y], Li[x][y], 0, 0, 0);
-                if (two) Lj[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[x], db[st][y], Lj[x][y], 0, 0, 0);
-            }
+            for (int y = 0; y < 2; ++y) Li[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[x], db[st][y], Li[x][y], 0, 0, 0);
     }
-    __syncthreads();                     // everyone has read the panel tiles: overwrite them with L_ik / L_jk
+    __syncthreads();                     // everyone has read tile i
+    if (two) {
+#pragma unroll
+        for (int v = 0; v < 8; ++v) *reinterpret_cast<double2*>(&R[(r8 + 8 * v) * LS + c2]) = a2v[v];
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            double a2[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) a2[x] = R[(32 * wm + 16 * x + lr) * LS + 4 * st + lq];
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) Lj[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[x], db[st][y], Lj[x][y], 0, 0, 0);
+        }
+        __syncthreads();                 // everyone has read tile j
+    }
+    // L_i through LDS: its [row][k] image feeds the A fragments of the update (kept in registers) and the stores
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -437,8 +456,7 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 32 * wm + 16 * x + lq + 4 * r, col = 32 * wn + 16 * y + lr;
-                R1[row * LS + col] = Li[x][y][r];
-                if (two) R2[row * LS + col] = Lj[x][y][r];
+                R[row * LS + col] = Li[x][y][r];
                 if (!inv_tile && tj == 0 && i0 + row < n) Lout[(size_t)(i0 + row) * ldl + k0 + col] = Li[x][y][r];
             }
     __syncthreads();
@@ -449,12 +467,26 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ 
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int rr = (tid >> 6) + 4 * v;         // row of Linv within the block = column of the C tile
-            if (k0 + rr < n && i0 + cc < n) Linv[(size_t)(k0 + rr) * ldi + i0 + cc] = R1[cc * LS + rr];
+            if (k0 + rr < n && i0 + cc < n) Linv[(size_t)(k0 + rr) * ldi + i0 + cc] = R[cc * LS + rr];
         }
     }
     if (panel_only) return;
-
-    const double* Rj = diag ? R1 : R2;
+    double af[16][2];
+#pragma unroll
+    for (int st = 0; st < 16; ++st)
+#pragma unroll
+        for (int x = 0; x < 2; ++x) af[st][x] = R[(32 * wm + 16 * x + lr) * LS + 4 * st + lq];
+    if (two) {
+        __syncthreads();                 // the A fragments (and the transposed store) are out of the image
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) R[(32 * wm + 16 * x + lq + 4 * r) * LS + 32 * wn + 16 * y + lr] = Lj[x][y][r];
+        __syncthreads();
+    }
+    // the update: S = L_i L_j^T (diagonal tile: L_i L_i^T), B fragments from the image of L_j
     d4 S[2][2];
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -462,17 +494,15 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ 
         for (int y = 0; y < 2; ++y) S[x][y] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int st = 0; st < 16; ++st) {
-        double a[2], b[2];
+        double b[2];
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            a[x] = R1[(32 * wm + 16 * x + lr) * LS + 4 * st + lq];
-            b[x] = Rj[(32 * wn + 16 * x + lr) * LS + 4 * st + lq];
-        }
+        for (int y = 0; y < 2; ++y) b[y] = R[(32 * wn + 16 * y + lr) * LS + 4 * st + lq];
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
-            for (int y = 0; y < 2; ++y) S[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], S[x][y], 0, 0, 0);
+            for (int y = 0; y < 2; ++y) S[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[st][x], b[y], S[x][y], 0, 0, 0);
     }
+    const bool next_diag = (Dinv_next != nullptr && blockIdx.x == 0);
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -480,13 +510,28 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = i0 + 32 * wm + 16 * x + lq + 4 * r, col = j0 + 32 * wn + 16 * y + lr;
-                if (row < n && col < n) Ct[(size_t)row * ldp + col] = Cij[x][y][r] - S[x][y][r];
+                Cij[x][y][r] -= S[x][y][r];
+                if (!next_diag && row < n && col < n) Ct[(size_t)row * ldp + col] = Cij[x][y][r];
             }
-    // The workgroup of tile (k+1, k+1) has just produced the next diagonal block: factor and invert it here,
-    // so the next step needs no separate (cold, 16 us) diagonal-block launch on the critical path.
-    if (Dinv_next != nullptr && blockIdx.x == 0) {
-        __syncthreads();                 // this workgroup's stores to A are visible to all of its threads
-        diag_block_body<true>(A, lda, n, k + 1, Dinv_next, nullptr, 0, info, nullptr, Lout, ldl, info_off, Rbuf);
+    // The workgroup of tile (k+1, k+1) has just produced the next diagonal block: it factors and inverts it on the
+    // spot, straight out of its registers (no round trip through memory: the work matrix never needs this tile
+    // again), so the next step needs no separate diagonal-block launch on the critical path.
+    if (next_diag) {
+        __syncthreads();                 // every wave is done with the image of L_i
+        double (*Lt)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(Rbuf);      // Lt[k][i] = block[i][k], identity padded
+        const int jb = min(NB, n - j0);
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 32 * wm + 16 * x + lq + 4 * r, col = 32 * wn + 16 * y + lr;
+                    const bool in = (row < jb) && (col < jb) && (col <= row);
+                    Lt[col][row] = in ? Cij[x][y][r] : ((row == col) ? 1.0 : 0.0);
+                }
+        __syncthreads();
+        diag_block_body<true, true>(A, lda, n, k + 1, Dinv_next, nullptr, 0, info, nullptr, Lout, ldl, info_off, Rbuf);
     }
 }
 

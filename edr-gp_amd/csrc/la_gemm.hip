@@ -887,11 +887,11 @@ __global__ void slab_reduce_kernel(const double* __restrict__ slabs, int splits,
 }
 
 template <int BM, int BN>
-static void launch_variant(bool akm, bool bkm, int tag, dim3 grid, hipStream_t s, const GemmArgs& g) {
+static void launch_variant(bool akm, bool bkm, int tag, dim3 grid, hipStream_t s, const GemmArgs& g, unsigned dyn_lds) {
     if (tag == 9 && akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, true, 9>), grid, dim3(256), 0, s, g);
     else if (tag == 1 && akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, true, 1>), grid, dim3(256), 0, s, g);
     else if (tag == 2 && !akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, true, 2>), grid, dim3(256), 0, s, g);
-    else if (tag == 3 && !akm && !bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, false, 3>), grid, dim3(256), 0, s, g);
+    else if (tag == 3 && !akm && !bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, false, 3>), grid, dim3(256), dyn_lds, s, g);
     else if (tag == 4 && !akm && !bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, false, 4>), grid, dim3(256), 0, s, g);
     else if (akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, true, 0>), grid, dim3(256), 0, s, g);
     else if (akm && !bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, false, 0>), grid, dim3(256), 0, s, g);
@@ -973,8 +973,8 @@ static int gemm_impl(Ctx* c, bool transA, bool transB, int M, int N, int K, doub
     const bool akm = transA;
     // op(B) is K x N: not transposed -> stored [K][N] (k-major); transposed -> stored [N][K]
     const bool bkm = !transB;
-    if (tile == 128) launch_variant<128, 128>(akm, bkm, o.tag, grid, c->stream, g);
-    else launch_variant<64, 64>(akm, bkm, o.tag, grid, c->stream, g);
+    if (tile == 128) launch_variant<128, 128>(akm, bkm, o.tag, grid, c->stream, g, (unsigned)o.dyn_lds);
+    else launch_variant<64, 64>(akm, bkm, o.tag, grid, c->stream, g, (unsigned)o.dyn_lds);
     HIP_TRY(hipGetLastError());
     return EDRGP_OK;
 }

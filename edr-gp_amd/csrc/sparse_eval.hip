@@ -111,6 +111,7 @@ struct SparseEval {
     bool k_resident = false;      // c->Knm holds K(X, Z) of all local rows
     bool prebuilt = false;        // K_nm (and b) of the single row chunk were built beside phase 1
     bool kmmi_done = false;       // Kmm^-1 = Li^T Li was formed on the side stream
+    bool kmmi_pending = false;    // ... and the main stream has not waited for it yet
     bool k32_resident = false;
     // precision 32 asks for the fp32 row pass; it is used while the Gram form is safe in fp32 (error ~ eps32
     // cond(Kmm), judged by the pivot-ratio proxy after phase 1), otherwise this evaluation falls back to the fp64
@@ -176,7 +177,7 @@ struct SparseEval {
         f32 = want32 && c->f32_phi && !c->phi32_bad;
         // the fused one-launch-per-step factorisation covers n in (64, 3072]; outside it the explicit inverse stays
         rhs_row = !need_grad && !need_post && c->chol_rhs && c->chol_fused && M > 64 && M + 1 <= 3072;
-        k_resident = prebuilt = kmmi_done = k32_resident = false;
+        k_resident = prebuilt = kmmi_done = kmmi_pending = k32_resident = false;
         return EDRGP_OK;
     }
 
@@ -381,8 +382,28 @@ struct SparseEval {
     }
 
     // ------------------------------------------------------------------ posterior / gradient pieces
+    // Kmm^-1 = Li^T Li is needed by the posterior / gradients only and depends on phase 1 alone: it runs on the side
+    // stream beside phase 3, whose factorisation is a chain of latency-bound steps that leave the chip almost idle
+    // (it used to sit in front of the Phi kernel: 0.21 ms on the critical path at M = 2048)
+    int kmmi_beside_phase3() {
+        if (!(need_grad || need_post) || !c->overlap || kmmi_done) return EDRGP_OK;
+        SideStream side(c);
+        TRY(side.start_after_main());              // after the row pass: the Phi kernel keeps the GPU to itself
+        {
+            ProfScope ps(c, EDRGP_PROF_SMALL);
+            TRY(gram_of_lower(c, M, Li, c->mats[MAT_KMMI].d()));
+        }
+        TRY(side.mark_done());
+        kmmi_done = kmmi_pending = true;
+        return EDRGP_OK;
+    }
+
     // R = LBi Li, P = R^T R, Kmm^-1 = Li^T Li
     int factors_queue() {
+        if (kmmi_pending) {
+            TRY(main_waits_side(c));
+            kmmi_pending = false;
+        }
         ProfScope ps(c, EDRGP_PROF_SMALL);
         double* R = c->mats[MAT_R].d();
         // R is lower triangular: lower tiles only, upper part stays zero
@@ -648,17 +669,22 @@ struct SparseEval {
         }
         if (can_prebuild) {
             {
+                // A workgroup of the build holds 36.9 KB of LDS, four per CU; a Cholesky step workgroup (42.5 KB)
+                // fits neither into the 12 KB left over nor -- LDS is allocated contiguously -- into the hole one
+                // retiring build workgroup leaves, so the steps of phase 1 starved until the build had drained
+                // (first step 456 us instead of 38).  Padded by `kbuild_pad` (16 KB: 53 KB per workgroup) the build runs
+                // three per CU and every hole it leaves takes a step workgroup of the high-priority side stream; the
+                // two then share the CUs (steps ~55 us, build 1.2 ms instead of 0.73) and the Phi kernel starts 0.15 ms
+                // earlier (Cm bound-only 10.25 -> 9.8 ms; padding 6 / 16 / 20 / 26 / 44 KB: 10.05 / 9.81 / 9.91 / 10.10 / 9.98).
                 ProfScope ps(c, EDRGP_PROF_KBUILD);
-                TRY(build_knm(0, N, c->Knm.d(), c->y.d(), bvec));
+                c->kbuild_pad_now = c->kbuild_pad;
+                const int st = build_knm(0, N, c->Knm.d(), c->y.d(), bvec);
+                c->kbuild_pad_now = 0;
+                if (st != EDRGP_OK) return st;
             }
             prebuilt = true;
             SideStream side(c);
             int st = phase1(careful);
-            if (st == EDRGP_OK && (need_grad || need_post)) {
-                ProfScope ps(c, EDRGP_PROF_SMALL);
-                st = gram_of_lower(c, M, Li, c->mats[MAT_KMMI].d());
-                kmmi_done = (st == EDRGP_OK);
-            }
             if (st == EDRGP_OK) st = side.join_into_main();
             return st;
         }
@@ -708,6 +734,7 @@ struct SparseEval {
         tr.mark("phase1 (+queued phase2)");
         if (!rows_done || stable || f32 != ran32) TRY(phase2(stable));
         tr.mark("phase2 queued");
+        TRY(kmmi_beside_phase3());
         {
             int st3 = phase3_careful(f32);
             if (f32) {
@@ -763,6 +790,7 @@ struct SparseEval {
         stable = assume_stable;
         if (!rows_done) TRY(phase2(stable));
         tr.mark("phase 1 + 2 queued");
+        TRY(kmmi_beside_phase3());
         TRY(phase3_queue(-1));
         TRY(finish_after_bound());
         if (need_grad) TRY(gradients_run());
