@@ -18,7 +18,7 @@ from sklearn.preprocessing import normalize as _row_normalize
 from sklearn.utils import check_array, check_X_y
 from sklearn.utils.validation import check_is_fitted
 
-from .utils import subspace_variance_ratio
+from .utils import GradientGram, subspace_variance_ratio
 
 
 def _require_components(transformer):
@@ -46,6 +46,13 @@ class BaseEDR(BaseEstimator, TransformerMixin):
     Attributes after fit: components_, estimator_, first_estimator_, transformer_,
     subspace_gradients_, subspace_variance_, subspace_variance_ratio_.
     """
+
+    # Device-side reduction (MI355X addition, no constructor parameter: the reference signature stays): when the
+    # estimator offers ``predict_gradient_gram`` and the transformer ``fit_gram`` (SVDTransformer), the gradients at
+    # the training rows are consumed as their D x D Gram matrix, reduced on the device -- no N x D copy to the host,
+    # no N x D SVD.  Components agree with the host path up to the sign of a singular vector.  False = always the
+    # reference's dense path.
+    device_reduction = True
 
     def __init__(self, estimator=None, transformer=None, n_components=None, step=None):
         self.estimator = estimator
@@ -80,14 +87,31 @@ class BaseEDR(BaseEstimator, TransformerMixin):
     def get_estimator_gradients(self, X):
         return self._get_estimator_gradients(check_array(X))
 
+    def _get_estimator_gradient_gram(self, X):
+        """``GradientGram`` of the estimator's gradients at X, or None when the device-side reduction does not
+        apply (estimator / transformer without the Gram interface, X not the estimator's training set)."""
+        if not (self.device_reduction and hasattr(self.estimator_, "predict_gradient_gram")
+                and hasattr(self.transformer, "fit_gram")):
+            return None
+        res = self.estimator_.predict_gradient_gram(X)
+        if res is None:
+            return None
+        gram, gsum, n = res
+        est, Xk = self.estimator_, X                # the dense matrix stays fetchable (refit by rows, user access)
+        return GradientGram(gram, n, gsum, fetch=lambda: est.predict_gradient(Xk))
+
     def _decompose(self, X):
         """Gradients at X -> freshly fitted transformer and its components."""
         check_is_fitted(self, "estimator_")
-        grad = self._get_estimator_gradients(X)
+        self.transformer_ = clone(self.transformer)
+        grad = self._get_estimator_gradient_gram(X)
+        if grad is not None:
+            self.transformer_.fit_gram(grad)
+        else:
+            grad = self._get_estimator_gradients(X)
+            self.transformer_.fit(grad)
         if self.num_iter == 0:
             self._first_gradients_ = grad
-        self.transformer_ = clone(self.transformer)
-        self.transformer_.fit(grad)
         _require_components(self.transformer_)
         return grad, deepcopy(self.transformer_.components_)
 
@@ -141,7 +165,19 @@ class BaseEDR(BaseEstimator, TransformerMixin):
         if refitted:
             check_is_fitted(self, ["refit_transformer_", "refit_components_"])
             return X @ self.refit_components_.T
-        return X @ self.components_.T
+        return self._project(X, self.components_.T)
+
+    def _project(self, X, W):
+        """X W on the host; the product is also announced to the device layer, so that a GP fitted on it next
+        (the EDR loop, edrgp/base.py:459-463) projects the resident rows on the device instead of uploading them."""
+        Xp = np.ascontiguousarray(X @ W)
+        if self.device_reduction:
+            try:
+                from .device import announce_projection
+                announce_projection(Xp, X, W)
+            except Exception:      # noqa: BLE001  (no native library: nothing to announce to)
+                pass
+        return Xp
 
     def inverse_transform(self, X):
         check_is_fitted(self, "components_")
@@ -285,7 +321,7 @@ class BlockEDR(BaseEDR):
     def _fit_transformer(self, X):
         check_is_fitted(self, "estimator_")
         self._make_blocks(X.shape[1])
-        grad = self._get_estimator_gradients(X)
+        grad = self._get_estimator_gradients(X)           # block-wise decompositions need the dense matrix
         if self.num_iter == 0:
             self._first_gradients_ = grad
         per_block = [self._fit_single_block(clone(self.transformer), grad, blk) for blk in self.blocks_]

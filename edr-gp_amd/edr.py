@@ -93,6 +93,13 @@ class EffectiveDimensionalityReduction(IterativeEDR):
             grad = grad @ self.components_
         return grad
 
+    def _get_estimator_gradient_gram(self, X):
+        G = super()._get_estimator_gradient_gram(X)
+        if G is not None and self.preprocessor is not None and self.num_iter == 0:
+            check_is_fitted(self, "preprocessor_")
+            G = G.mapped(self._preprocessing_)       # first iteration: gradients live in preprocessor coordinates
+        return G
+
     @property
     def feature_importances_(self):
         check_is_fitted(self, "components_")
@@ -108,4 +115,4 @@ class EffectiveDimensionalityReduction(IterativeEDR):
         comps = self.components_
         if not self.fitted and self.preprocessor is not None:
             comps = comps @ self._preprocessing_.T     # still inside fit: X is in preprocessor coordinates
-        return X @ comps.T
+        return self._project(X, comps.T) if not self.fitted else X @ comps.T

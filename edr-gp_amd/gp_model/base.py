@@ -82,6 +82,14 @@ class _BaseGP(BaseEstimator, metaclass=ABCMeta):
         X = self._check_predict(X)
         return self.estimator_.predictive_gradients(X)[0][:, :, 0]
 
+    def predict_gradient_gram(self, X):
+        """An addition to the reference interface: ``(G^T G, column sums of G, n_samples)`` for G = predict_gradient(X)
+        when X is the training set -- reduced on the device, the n_samples x n_features matrix G stays in HBM -- and
+        None otherwise.  The EDR estimators use it when their transformer can decompose a Gram matrix
+        (``SVDTransformer.fit_gram``)."""
+        X = self._check_predict(X)
+        return self.estimator_.predictive_gradient_gram(X)
+
     def save(self, model_path):
         """Writes the model to ``model_path`` (+ '.pickle', the reference's suffix rule,
         base.py:237-239).  The file is an .npz archive of arrays, not a Python pickle."""

@@ -118,7 +118,7 @@ class HipEvaluator:
             self._sent["prec"] = prec
             self._sent.pop("post", None)
         if self._sent.get("data") is not model._data_version:
-            h.set_data(model.X, model.Y_normalized[:, 0])
+            self._ctx.send_data(model.X, model.Y_normalized[:, 0])
             self._sent = {"data": model._data_version, "prec": prec}
         if model.is_sparse:
             zkey = model.Z.tobytes()
@@ -162,6 +162,11 @@ class HipEvaluator:
 
     def predict_train(self, model, want_mean=True, want_grad=True):
         return self._ensure_posterior(model).predict_train(want_mean, want_grad)
+
+    def predict_train_gram(self, model):
+        """J^T J (D x D) and column sums of the mean Jacobian J at the training rows, reduced on the device."""
+        _, gram, gsum = self._ensure_posterior(model).predict_train_gram(want_mean=False)
+        return gram, gsum
 
     def posterior_factors(self, model):
         h = self._ensure_posterior(model)
@@ -390,6 +395,24 @@ class _GPModel:
         if self.normalizer is not None:
             jac = jac * self.normalizer.std
         return jac[:, :, None], None
+
+    def predictive_gradient_gram(self, Xnew):
+        """G^T G (D x D) and the column sums of G = d mean / d x* (un-normalised mean) at the TRAINING inputs, without
+        moving the N x D matrix G to the host: what the EDR step consumes (edrgp/base.py:459-463 -> a linear
+        decomposition of G).  Returns None when Xnew is not the training set (the caller then takes
+        ``predictive_gradients``)."""
+        Xnew = np.asarray(Xnew, dtype=np.float64)
+        if Xnew.shape != self.X.shape or not np.array_equal(Xnew, self.X):
+            return None
+        if hasattr(self._evaluator, "predict_train_gram"):
+            gram, gsum = self._evaluator.predict_train_gram(self)
+        else:                                        # evaluators without the device-side reduction (tests)
+            _, jac = self._evaluator.predict_train(self, want_mean=False, want_grad=True)
+            gram, gsum = jac.T @ jac, jac.sum(0)
+        if self.normalizer is not None:
+            std = float(np.ravel(self.normalizer.std)[0])
+            gram, gsum = gram * std * std, gsum * std
+        return gram, gsum, self.num_data
 
     # -- persistence (replaces GPy's pickle: data, parameters, no code) -----------
     def to_dict(self):

@@ -17,12 +17,54 @@ def ort_space(A):
     return U[:, rank:]
 
 
+class GradientGram:
+    """An (n_samples x n_features) gradient matrix known through its Gram matrix G^T G (and column sums): what the
+    EDR step needs of the posterior-mean gradients at the training rows (edrgp/base.py:459-463 feeds them to a
+    linear decomposition, edrgp/utils.py:27-55 to norms of projections).  The MI355X estimators reduce G^T G on the
+    device (``edrgp_predict_train_gram``), so the N x D matrix itself never crosses PCIe; ``materialize()`` fetches
+    it on demand (row-indexed refits, BlockEDR, user access) through the callable given at construction."""
+
+    def __init__(self, gram, n_samples, gsum=None, fetch=None):
+        self.gram = np.asarray(gram, dtype=np.float64)
+        self.gsum = None if gsum is None else np.asarray(gsum, dtype=np.float64)
+        self.shape = (int(n_samples), self.gram.shape[0])
+        self._fetch = fetch
+        self._dense = None
+
+    def materialize(self):
+        if self._dense is None:
+            if self._fetch is None:
+                raise ValueError("the gradient matrix behind this Gram matrix is not available")
+            self._dense = np.asarray(self._fetch(), dtype=np.float64)
+        return self._dense
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.materialize()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    def __getitem__(self, idx):
+        return self.materialize()[idx]
+
+    def mapped(self, P):
+        """Gram matrix of G P (P: n_features x k)."""
+        fetch = None if self._fetch is None else (lambda: self.materialize() @ P)
+        return GradientGram(P.T @ self.gram @ P, self.shape[0], None if self.gsum is None else self.gsum @ P, fetch)
+
+
 def subspace_variance_ratio(X, V):
     """Norm of X projected on the columns of V, and its squared share of ||X||_F.
     Per column when V is orthonormal, otherwise one number for span(V)
-    (edrgp/utils.py:27-55)."""
+    (edrgp/utils.py:27-55).  X may be a ``GradientGram``: ||X v||^2 = v^T (X^T X) v."""
     gram = V.T @ V
-    if np.allclose(gram, np.eye(V.shape[1])):
+    ortho = np.allclose(gram, np.eye(V.shape[1]))
+    if isinstance(X, GradientGram):
+        if ortho:
+            proj = np.sqrt(np.clip(np.einsum("ij,ik,kj->j", V, X.gram, V), 0.0, None))
+        else:
+            Q = np.linalg.qr(V)[0]
+            proj = np.sqrt(max(np.trace(Q.T @ X.gram @ Q), 0.0))
+        return proj, (proj / np.sqrt(np.trace(X.gram))) ** 2
+    if ortho:
         proj = np.linalg.norm(X @ V, axis=0)
     else:
         Q = np.linalg.qr(V)[0]
@@ -56,22 +98,41 @@ class SVDTransformer(BaseEstimator, TransformerMixin):
         # edrgp/utils.py:140, which also builds the n_samples x n_samples U: 20 GB and 13 s per call at
         # 50 000 gradient rows; S and V^T are the same.)
         _, S, Vh = np.linalg.svd(Xc, full_matrices=False)
-        var = S ** 2
+        return self._select(S ** 2, Vh, Xc.shape[0])
+
+    def _select(self, var, Vh, n_rows):
         ratio = var / var.sum()
-        k = Xc.shape[1]
+        k = Vh.shape[1]
         nc = self.n_components
-        if isinstance(nc, (int, np.integer)) and not isinstance(nc, bool) and 0 < nc <= Xc.shape[1]:
+        if isinstance(nc, (int, np.integer)) and not isinstance(nc, bool) and 0 < nc <= Vh.shape[1]:
             k = int(nc)
         elif isinstance(nc, float) and 0 < nc < 1:
             # (the reference raises NameError here: undefined `expl_var_ratio`, utils.py:148-150)
             k = int(np.sum(np.cumsum(ratio) < nc)) + 1
         elif nc is True:
             k = 1                      # examples/regression.py passes True positionally
-        k = min(Xc.shape[0], k)
+        k = min(n_rows, k)
         self.components_ = Vh[:k, :]
         self.subspace_variance_ = var[:k]
         self.subspace_variance_ratio_ = ratio[:k]
         return self
+
+    def fit_gram(self, G):
+        """The same decomposition from the Gram matrix X^T X alone (a ``GradientGram``): the right singular vectors
+        of X are the eigenvectors of X^T X, the squared singular values its eigenvalues.  Signs: a singular vector
+        is defined up to sign; here each component is oriented along the column sums of X (largest entry positive
+        when those are unknown or orthogonal to it)."""
+        w, V = np.linalg.eigh(G.gram)
+        order = np.argsort(w)[::-1]
+        var = np.clip(w[order], 0.0, None)
+        Vh = V[:, order].T.copy()
+        for i in range(Vh.shape[0]):
+            d = 0.0 if G.gsum is None else float(Vh[i] @ G.gsum)
+            if abs(d) <= 1e-12 * max(1.0, float(np.abs(G.gsum).max()) if G.gsum is not None else 1.0):
+                d = Vh[i, np.argmax(np.abs(Vh[i]))]
+            if d < 0:
+                Vh[i] = -Vh[i]
+        return self._select(var, Vh, G.shape[0])
 
     def transform(self, X):
         return np.asarray(X).dot(self.components_.T)

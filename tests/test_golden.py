@@ -161,7 +161,70 @@ def test_base_block_and_utils_match_reference(edr_gold):
     assert SVDTransformer(n_components=0.9).fit(edr_gold["svd_in"]).components_.shape[0] >= 1
 
 
-def test_iterative_edr_matches_reference_on_gp_gradients(monkeypatch):
+def _sign_rows(C):
+    """Each row oriented so that its entry of largest magnitude is positive (a singular vector's sign is free)."""
+    C = np.array(C, dtype=float, copy=True)
+    for r in C:
+        if r[np.argmax(np.abs(r))] < 0:
+            r *= -1.0
+    return C
+
+
+class GramTanhRidgeEstimator(TanhRidgeEstimator):
+    """The duck estimator with the Gram interface of the MI355X regressors (``predict_gradient_gram``): drives the
+    EDR layer's device-reduction path (GradientGram / SVDTransformer.fit_gram) without a GPU."""
+
+    def fit(self, X, y, **kw):
+        self.X_fit_ = np.asarray(X, dtype=float)
+        return super().fit(X, y, **kw)
+
+    def predict_gradient_gram(self, X):
+        X = np.asarray(X, dtype=float)
+        if X.shape != self.X_fit_.shape or not np.array_equal(X, self.X_fit_):
+            return None
+        G = self.predict_gradient(X)
+        return G.T @ G, G.sum(0), G.shape[0]
+
+
+@pytest.mark.parametrize("name,cfg", [
+    ("oneshot", dict(n_components=2, step=None, normalize=True, preprocessor=None)),
+    ("nonorm", dict(n_components=2, step=None, normalize=False, preprocessor=None)),
+    ("iter_int", dict(n_components=2, step=2, normalize=True, preprocessor=None)),
+    ("iter_float", dict(n_components=None, step=0.9, normalize=True, preprocessor=None)),
+    ("pca_pre", dict(n_components=1, step=None, normalize=True, preprocessor=PCA(n_components=4))),
+])
+def test_edr_gram_path_matches_reference_edr_layer(edr_gold, name, cfg):
+    """The device-reduction path of the EDR layer (gradients consumed as G^T G, never as an N x D matrix; projected
+    refits announced to the device layer) reproduces the REFERENCE's fixtures to 1e-9, the free sign of each
+    singular vector normalised on both sides."""
+    from edrgp_amd.edr import EffectiveDimensionalityReduction
+    from edrgp_amd.utils import GradientGram, SVDTransformer
+    X, y = edr_gold["X"], edr_gold["y"]
+    edr = EffectiveDimensionalityReduction(GramTanhRidgeEstimator(), SVDTransformer(), cfg["n_components"], cfg["step"],
+                                           cfg["normalize"], cfg["preprocessor"])
+    edr.fit(X, y)
+    assert isinstance(edr._first_gradients_, GradientGram)          # the Gram path really ran
+    assert edr.num_iter == int(edr_gold[name + "_num_iter"])
+    ref = edr_gold[name + "_components"]
+    # The duck estimator's gradients are all parallel to one vector: G has rank 1, and a direction of zero variance
+    # is ANY unit vector of the null space (the SVD of G and the eigen-decomposition of G^T G pick different ones).
+    # Components are compared where they are defined: those that carry variance.
+    live = np.atleast_1d(edr_gold[name + "_subspace_variance_ratio"]) > 1e-10
+    assert live.any()
+    assert close(_sign_rows(edr.components_)[live], _sign_rows(ref)[live])
+    assert close(np.atleast_1d(edr.subspace_variance_), edr_gold[name + "_subspace_variance"], 1e-8)
+    assert close(np.atleast_1d(edr.subspace_variance_ratio_), edr_gold[name + "_subspace_variance_ratio"], 1e-8)
+    sgn = np.sign(np.sum(edr.components_ * ref, axis=1))             # row signs relative to the reference
+    assert close((edr.transform(X) * sgn)[:, live], edr_gold[name + "_transform"][:, live])
+    assert close((edr.feature_importances_ * sgn[:, None])[live], edr_gold[name + "_feature_importances"][live])
+    assert close(edr.get_estimator_gradients(X[:10]), edr_gold[name + "_gradients"])      # back in input coordinates: sign-free
+    # the dense matrix behind the Gram matrix is still there on demand (refit by rows, user access)
+    dense = np.asarray(edr._first_gradients_)
+    assert dense.shape == X.shape and close(dense.T @ dense, edr._first_gradients_.gram, 1e-12)
+
+
+@pytest.mark.parametrize("device_reduction", [False, True])
+def test_iterative_edr_matches_reference_on_gp_gradients(monkeypatch, device_reduction):
     """iter_golden.npz (tests/golden/make_iter_golden.py): the reference's iterative EDR with the adaptive step
     0.99 on the data of its own test_iterative, fed with GP gradients.  This repository's EDR layer, driven by
     the same (oracle-answered) GP, must keep the same 3 directions after the same 3 iterations."""
@@ -174,10 +237,14 @@ def test_iterative_edr_matches_reference_on_gp_gradients(monkeypatch):
     g = np.load(os.path.join(GOLD, "iter_golden.npz"), allow_pickle=False)
     edr = EffectiveDimensionalityReduction(GaussianProcessRegressor(['RBF'], [{'ARD': True}]), SVDTransformer(),
                                            n_components=None, step=0.99, normalize=False)
+    edr.device_reduction = device_reduction     # True: gradients consumed as G^T G (here reduced by the oracle evaluator)
     edr.fit(g["X"], g["y"])
     assert edr.num_iter == int(g["num_iter"]) == 3
     assert edr.components_.shape == (3, 10)
-    assert close(edr._first_gradients_, g["first_gradients"], 1e-7)
-    assert close(edr.components_, g["components"], 1e-6)
-    assert close(np.atleast_1d(edr.subspace_variance_ratio_), g["subspace_variance_ratio"], 1e-6)
+    assert close(np.asarray(edr._first_gradients_), g["first_gradients"], 1e-7)
+    # Gram path: singular vectors come with the other sign convention, and the GP refits on mirrored projections
+    # stop at slightly different optimiser iterates (2e-5 observed in the trailing component)
+    tol = 1e-4 if device_reduction else 1e-6
+    assert close(_sign_rows(edr.components_), _sign_rows(g["components"]), tol)
+    assert close(np.atleast_1d(edr.subspace_variance_ratio_), g["subspace_variance_ratio"], tol)
     assert discrepancy(g["B"], edr.components_.T) < 1e-1          # upstream's own assertion

@@ -14,11 +14,30 @@ y = np.tanh(X @ B[0]) + 0.5 * (X @ B[1]) ** 2 + 0.05 * rng.standard_normal(N)
 np.random.seed(0)
 edr = EffectiveDimensionalityReduction(SparseGaussianProcessRegressor(num_inducing=MIND, kernel_options=None),
                                        SVDTransformer(), n_components=2, normalize=True)
-pr = cProfile.Profile(); pr.enable()
-t0 = time.perf_counter()
-edr.fit(X, y, max_iters=30)
-dt = time.perf_counter() - t0
-pr.disable()
-print("EDR fit: %.2f s; subspace discrepancy vs the true directions: %.4f; variance ratios %s"
-      % (dt, discrepancy(B, edr.components_), np.round(edr.subspace_variance_ratio_, 4)))
-pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+from edrgp_amd.backend import HipGP
+from edrgp_amd.device import shared_context
+d2h = {"bytes": 0}
+_orig = HipGP.predict_train
+def _counted(self, want_mean=True, want_grad=True):
+    d2h["bytes"] += 8 * self.N * ((self.D if want_grad else 0) + (1 if want_mean else 0))
+    return _orig(self, want_mean, want_grad)
+HipGP.predict_train = _counted
+for device_reduction in (True, False):
+    np.random.seed(0)
+    edr = EffectiveDimensionalityReduction(SparseGaussianProcessRegressor(num_inducing=MIND, kernel_options=None),
+                                           SVDTransformer(), n_components=2, normalize=True)
+    edr.device_reduction = device_reduction
+    d2h["bytes"] = 0
+    sends0 = shared_context().projected_sends
+    pr = cProfile.Profile(); pr.enable()
+    t0 = time.perf_counter()
+    edr.fit(X, y, max_iters=30)
+    dt = time.perf_counter() - t0
+    pr.disable()
+    print("EDR fit (device_reduction=%s): %.2f s, %d outer iterations; gradient bytes copied to the host %.1f MB; data sets "
+          "projected on the device %d; subspace discrepancy vs the true directions: %.4f; variance ratios %s"
+          % (device_reduction, dt, edr.num_iter, d2h["bytes"] / 1e6, shared_context().projected_sends - sends0,
+             discrepancy(B.T / np.linalg.norm(B.T, axis=0), np.linalg.qr(edr.components_.T)[0]),
+             np.round(edr.subspace_variance_ratio_, 4)), flush=True)
+    if len(sys.argv) > 4:
+        pstats.Stats(pr).sort_stats("tottime").print_stats(10)
