@@ -31,6 +31,8 @@ def announce_projection(X_proj, base, W):
     if isinstance(X_proj, np.ndarray) and X_proj.dtype == np.float64 and X_proj.flags["C_CONTIGUOUS"]:
         _projections[_key(X_proj)] = (X_proj, np.ascontiguousarray(base, dtype=np.float64),
                                       np.ascontiguousarray(W, dtype=np.float64))
+        while len(_projections) > 4:          # only the latest products matter (one per EDR iteration)
+            _projections.pop(next(iter(_projections)))
 
 
 def forget_projections():
