@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libedrgp_hip.so")
+LIB_PATH = os.environ.get("EDRGP_LIB", os.path.join(_HERE, "libedrgp_hip.so"))   # EDRGP_LIB: another build of the same library (A/B runs)
 
 # status codes (include/edrgp_hip.h)
 OK, ERR_INVALID, ERR_NOT_PD, ERR_HIP, ERR_STATE, ERR_COMM = 0, -1, -2, -3, -4, -5

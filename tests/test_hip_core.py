@@ -331,6 +331,36 @@ def test_dense_lml_gradients_predict(hip, N, D, kinds, opts, noise):
     assert rel(hip.predict_grad(Xs), jac_ref) < 1e-8
 
 
+@pytest.mark.parametrize("N,D,kind", [(2500, 6, "RBF"), (4100, 8, "Matern52")])
+def test_dense_exact_gp_beyond_the_plumbing_size(hip, N, D, kind):
+    """the exact GP (edrgp/gp_model/regression.py:10-77) at sizes beyond config 1's N = 500.  N = 2500
+    runs the fused factorisation + inverse (one launch per 64-column step), N = 4100 the path beyond 3072
+    (two launches per step, recursive-doubling inverse).  Bound, gradients, posterior mean / variance / Jacobian
+    against the oracle."""
+    X, y, _ = go.synthetic_problem(N, D, 4, seed=N)
+    kern = go.make_kernel([kind], D, [dict(variance=0.9, lengthscale=0.8 * np.sqrt(D))])
+    noise = 0.05
+    inf = go.exact_inference(kern, X, noise, y[:, None])
+    kg, dn = go.dense_gradients(kern, X, inf)
+    hip.set_data(X, y)
+    set_kernel(hip, kern, noise)
+    lml, dvar, dlen, dnoise = hip.dense_lml_grad()
+    # (a sum of N terms of order one that nearly cancels: measured against max(|LML|, N))
+    assert abs(lml - inf["log_marginal"]) <= 1e-10 * max(abs(inf["log_marginal"]), float(N))
+    gscale = max(abs(dn), abs(kg[0][0]), np.abs(kg[0][1]).max())
+    assert abs(dvar[0] - kg[0][0]) <= 1e-8 * gscale
+    assert np.abs(fold_dlen(kern, dlen)[0] - kg[0][1]).max() <= 1e-8 * gscale
+    assert abs(dnoise - dn) <= 1e-8 * gscale
+    hip.dense_posterior()
+    Xs = np.vstack([np.random.default_rng(2).standard_normal((40, D)), X[:8]])
+    mu_ref, var_ref = go.raw_predict(kern, Xs, X, inf["woodbury_vector"], inf["woodbury_inv"])
+    jac_ref = go.predictive_gradients_mean(kern, Xs, X, inf["woodbury_vector"])[:, :, 0]
+    mu, var = hip.predict(Xs)
+    assert rel(mu, mu_ref[:, 0]) < 1e-8
+    assert np.abs(var - var_ref[:, 0]).max() < 1e-8 * max(1.0, np.abs(var_ref).max())
+    assert rel(hip.predict_grad(Xs), jac_ref) < 1e-8
+
+
 def test_bitwise_reproducible_across_overlap_modes(hip):
     """Fixed-order reductions, no float atomics: the same evaluation gives the same bits on every repeat,
     whichever side-stream overlap policy schedules it."""
