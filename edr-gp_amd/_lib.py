@@ -66,6 +66,8 @@ PROTOTYPES = {
     "edrgp_predict_grad": [_ctx_p, _c_double_p, ctypes.c_int64, _c_double_p],
     "edrgp_predict_train": [_ctx_p, _c_double_p, _c_double_p],
     "edrgp_predict_train_gram": [_ctx_p, _c_double_p, _c_double_p, _c_double_p],
+    "edrgp_sweep_scales": [_ctx_p, ctypes.c_int, _c_double_p, ctypes.c_double, ctypes.c_double, ctypes.c_int, _c_double_p,
+                           _c_double_p, _c_double_p, _c_int_p],
     "edrgp_get": [_ctx_p, ctypes.c_int, _c_double_p, ctypes.c_int64],
     "edrgp_profile_reset": [_ctx_p],
     "edrgp_profile_get": [_ctx_p, ctypes.c_int, _c_double_p, _c_i64_p],

@@ -165,6 +165,22 @@ class HipGP:
         check(self._lib.edrgp_predict_train_gram(self._ctx, dptr(mean), dptr(gram), dptr(gsum)))
         return mean, gram, gsum
 
+    def sweep_scales(self, lengthscales, variance=1.0, noise_var=0.01, kind="RBF", want_gram=True):
+        """Bound (and J^T J / column sums of the mean Jacobian at the training rows) for a grid of isotropic
+        length-scales of the resident rows and inducing inputs, as ONE batch on the device.
+        Returns (bounds[G], grams[G, D, D] or None, gsums[G, D] or None, modes[G]); mode -1 = not evaluated
+        (needs jitter: take the per-unit path for that scale)."""
+        ls = as_f64(lengthscales).ravel()
+        G = ls.size
+        bounds = np.empty(G)
+        grams = np.empty((G, self.D, self.D)) if want_gram else None
+        gsums = np.empty((G, self.D)) if want_gram else None
+        modes = np.zeros(G, dtype=np.int32)
+        check(self._lib.edrgp_sweep_scales(self._ctx, G, dptr(ls), float(variance), float(noise_var), KERN_CODES[kind],
+                                           dptr(bounds), dptr(grams), dptr(gsums),
+                                           modes.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+        return bounds, grams, gsums, modes
+
     # -- parity / profiling accessors --------------------------------------
     def get(self, name, shape):
         buf = np.empty(shape)

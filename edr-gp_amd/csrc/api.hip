@@ -611,6 +611,12 @@ int edrgp_predict_train_gram(edrgp_ctx* ctx, double* mean, double* gram, double*
     return predict_rows(c, c->X.d(), c->N, mean, nullptr, nullptr, gram, gsum);
 }
 
+int edrgp_sweep_scales(edrgp_ctx* ctx, int nscales, const double* lengthscales, double variance, double noise_var,
+                       int kind, double* bounds, double* grams, double* gsums, int* modes) {
+    CTX(ctx);
+    return sweep_scales(c, nscales, lengthscales, variance, noise_var, kind, bounds, grams, gsums, modes);
+}
+
 int edrgp_get(edrgp_ctx* ctx, int which, double* buf, int64_t cap) {
     CTX(ctx);
     if (!buf) return EDRGP_ERR_INVALID;

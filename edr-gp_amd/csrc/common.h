@@ -147,6 +147,8 @@ int potrf_lower(Ctx* c, double* A, int n, int lda, int* info_dev);
 int trtri_lower(Ctx* c, const double* L, int ldl, double* Linv, int ldi, int n);
 // both at once (one launch per 64-column step for n in (64, 3072]: la_chol.hip)
 int potrf_inv_lower(Ctx* c, double* A, int n, int lda, int* info_dev, double* Linv, int ldi);
+int potrf_inv_lower_batched(Ctx* c, double* A, int n, int lda, long long strideA, int* info_dev, double* Linv, int ldi,
+                            long long strideI, int batch);
 int diag_block_stamps(Ctx* c, double* A64, double* Dinv64, unsigned long long* stamps_dev, int do_chol);
 
 // -------------------------------------------------------------- vector helpers
@@ -302,6 +304,8 @@ struct Ctx {
     DBuf g2;                          // T^T [X | X.^2] and column sums of T (fused gradient path)
     DBuf slabs, bpart, scal, info, gt_nm, gt_mm, tmpvec[6], panel, trtri_ws, dinv, red, lbaug;
     DBuf pack;                        // lower triangle of Phi and b, packed for the all-reduce
+    DBuf sw_small, sw_r2, sw_mats, sw_kall;   // batched length-scale sweep (sweep_eval.hip)
+    bool kbuild_r2 = false;           // the MFMA build stores r^2 instead of k(r^2) (set around the sweep's distance pass)
     std::vector<double> host_scal;
     std::vector<double> Z_host;       // host copy of the inducing inputs (gradient finishing)
     double* h_stage = nullptr;        // pinned staging of the gradient tables
@@ -323,5 +327,8 @@ struct Ctx {
 };
 
 int allreduce_sum(Ctx* c, double* buf, size_t count);
+// bound / woodbury vector / gradient Gram matrix for G isotropic length-scales of the resident rows and Z as one batch
+int sweep_scales(Ctx* c, int G, const double* lengthscales, double var, double noise_var, int kind, double* bounds,
+                 double* grams, double* gsums, int* modes);
 
 }  // namespace edrgp

@@ -270,7 +270,7 @@ static int kernel_matrix_mfma(Ctx* c, const KSpec& ks, const double* X, int64_t 
     const int tiles_m = (int)((rows + tile - 1) / tile);
     FuseK f;
     f.xn = c->ks_xn.d(); f.zn = zn; f.y = y; f.bpart = nullptr;
-    f.var = ks.var[0]; f.jitter = jitter; f.kind = ks.kind[0]; f.same = same; f.dbg = same ? 0 : c->kbuild_dbg;
+    f.var = ks.var[0]; f.jitter = jitter; f.kind = ks.kind[0]; f.same = same; f.dbg = c->kbuild_r2 ? 1 : (same ? 0 : c->kbuild_dbg);
     if (y != nullptr) {
         TRY(c->bpart.reserve((size_t)tiles_m * M2 * sizeof(double)));
         f.bpart = c->bpart.d();

@@ -262,6 +262,12 @@ __device__ __forceinline__ void diag_block_body(double* __restrict__ Abase, int 
 #undef EDRGP_STAMP
 }
 
+// Strides of a batch of independent matrices (blockIdx.y of the factorisation kernels); all zero = one matrix.
+struct CholBatch {
+    long long sA = 0, sL = 0, sD = 0, sC = 0, sI = 0;   // work matrix, factor workspace, Dinv slabs, C rows, inverse
+    int sInfo = 0;
+};
+
 template <bool DO_CHOL>
 __global__ __launch_bounds__(256) void diag_block_kernel(double* __restrict__ Abase, int lda, int n,
                                                         int first_block, double* __restrict__ Dinv,
@@ -269,11 +275,13 @@ __global__ __launch_bounds__(256) void diag_block_kernel(double* __restrict__ Ab
                                                         int* __restrict__ info,
                                                         unsigned long long* __restrict__ stamps,
                                                         double* __restrict__ Lbase = nullptr, int ldlo = 0,
-                                                        int info_off = 0) {
+                                                        int info_off = 0, CholBatch bt = CholBatch()) {
     __shared__ __attribute__((aligned(16))) double lds[DIAG_LDS];
-    diag_block_body<DO_CHOL>(Abase, lda, n, first_block + (int)blockIdx.x,
-                             Dinv ? Dinv + (size_t)blockIdx.x * NB * NB : nullptr, inv_out, ldi, info, stamps, Lbase, ldlo,
-                             info_off, lds);
+    const long long z = blockIdx.y;
+    diag_block_body<DO_CHOL>(Abase + z * bt.sA, lda, n, first_block + (int)blockIdx.x,
+                             Dinv ? Dinv + z * bt.sD + (size_t)blockIdx.x * NB * NB : nullptr,
+                             inv_out ? inv_out + z * bt.sI : nullptr, ldi, info ? info + z * bt.sInfo : nullptr, stamps,
+                             Lbase ? Lbase + z * bt.sL : nullptr, ldlo, info_off, lds);
 }
 
 // one factor+invert of a 64x64 block with phase stamps: diagnostic only
@@ -337,10 +345,21 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ 
                                                            int ldl, const double* __restrict__ Dinv, int n, int k,
                                                            double* __restrict__ Dinv_next, int* __restrict__ info,
                                                            int info_off, int ntri, double* __restrict__ Cw, int ldc,
-                                                           double* __restrict__ Linv, int ldi, int panel_only) {
+                                                           double* __restrict__ Linv, int ldi, int panel_only,
+                                                           CholBatch bt) {
     constexpr int LS = NB + 2;
     constexpr int LDS_DOUBLES = (NB * LS > DIAG_LDS) ? NB * LS : DIAG_LDS;
     __shared__ __attribute__((aligned(16))) double Rbuf[LDS_DOUBLES];
+    {   // blockIdx.y: one of a batch of independent factorisations advancing in the same launches
+        const long long z = blockIdx.y;
+        A += z * bt.sA;
+        Lout += z * bt.sL;
+        Dinv += z * bt.sD;
+        if (Dinv_next != nullptr) Dinv_next += z * bt.sD;
+        if (info != nullptr) info += z * bt.sInfo;
+        if (Cw != nullptr) Cw += z * bt.sC;
+        if (Linv != nullptr) Linv += z * bt.sI;
+    }
     double* R = Rbuf;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lq = lane >> 4;
@@ -536,9 +555,12 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ 
 }
 
 // A = lower triangle of L (explicit zeros above the diagonal)
-__global__ void take_lower_kernel(double* __restrict__ A, int lda, const double* __restrict__ L, int ldl, int n) {
+__global__ void take_lower_kernel(double* __restrict__ A, int lda, const double* __restrict__ L, int ldl, int n,
+                                  long long sA = 0, long long sL = 0) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y * blockDim.y + threadIdx.y;
+    A += (long long)blockIdx.z * sA;
+    L += (long long)blockIdx.z * sL;
     if (i < n && j < n) A[(size_t)i * lda + j] = (j <= i) ? L[(size_t)i * ldl + j] : 0.0;
 }
 
@@ -546,47 +568,70 @@ __global__ void take_lower_kernel(double* __restrict__ A, int lda, const double*
 // copied back, A is the work matrix of the trailing updates.  With Linv != nullptr the inverse L^-1 comes out of
 // the same launches (see chol_step_kernel).
 static int potrf_lower_fused(Ctx* c, double* A, int n, int lda, int* info_dev, bool reset_info = true,
-                             int info_off = 0, double* Linv = nullptr, int ldi = 0) {
-    if (reset_info) HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), c->stream));
-    if (c->dinv.bytes < (size_t)2 * NB * NB * sizeof(double)) {
-        TRY(c->dinv.reserve((size_t)2 * NB * NB * sizeof(double)));
+                             int info_off = 0, double* Linv = nullptr, int ldi = 0, int batch = 1, long long strideA = 0,
+                             long long strideI = 0) {
+    const size_t G = (size_t)std::max(1, batch);
+    if (reset_info) HIP_TRY(hipMemsetAsync(info_dev, 0, G * sizeof(int), c->stream));
+    if (c->dinv.bytes < G * 2 * NB * NB * sizeof(double)) {
+        TRY(c->dinv.reserve(G * 2 * NB * NB * sizeof(double)));
         // blocks above the diagonal are never written by the kernel
-        HIP_TRY(hipMemsetAsync(c->dinv.d(), 0, (size_t)2 * NB * NB * sizeof(double), c->stream));
+        HIP_TRY(hipMemsetAsync(c->dinv.d(), 0, G * 2 * NB * NB * sizeof(double), c->stream));
     }
-    TRY(c->panel.reserve((size_t)n * n * sizeof(double)));
+    TRY(c->panel.reserve(G * n * n * sizeof(double)));
     double* Dinv = c->dinv.d();                       // two slabs: step b reads [b & 1] and writes [(b + 1) & 1]
     double* Lw = c->panel.d();
     double* Cw = nullptr;
+    CholBatch bt;
+    if (batch > 1) {
+        bt.sA = strideA;
+        bt.sL = (long long)n * n;
+        bt.sD = 2LL * NB * NB;
+        bt.sC = (long long)n * n;
+        bt.sI = strideI;
+        bt.sInfo = 1;
+    }
     if (Linv != nullptr) {
-        TRY(c->trtri_ws.reserve((size_t)n * n * sizeof(double)));
+        TRY(c->trtri_ws.reserve(G * n * n * sizeof(double)));
         Cw = c->trtri_ws.d();                         // the appended identity rows (never initialised: see the kernel)
-        if (ldi == n) {
-            hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, c->stream, Linv, (size_t)n * n, 0.0);
-        } else {
-            HIP_TRY(hipMemset2DAsync(Linv, (size_t)ldi * sizeof(double), 0, (size_t)n * sizeof(double), (size_t)n, c->stream));
+        for (size_t z = 0; z < G; ++z) {
+            double* Lz = Linv + z * (size_t)strideI;
+            if (ldi == n) {
+                hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, c->stream, Lz, (size_t)n * n, 0.0);
+            } else {
+                HIP_TRY(hipMemset2DAsync(Lz, (size_t)ldi * sizeof(double), 0, (size_t)n * sizeof(double), (size_t)n, c->stream));
+            }
         }
     }
     const int nblk = (n + NB - 1) / NB;
-    hipLaunchKernelGGL(diag_block_kernel<true>, dim3(1), dim3(256), 0, c->stream, A, lda, n, 0, Dinv, (double*)nullptr, 0,
-                       info_dev, (unsigned long long*)nullptr, Lw, n, info_off);
+    hipLaunchKernelGGL(diag_block_kernel<true>, dim3(1, (unsigned)G), dim3(256), 0, c->stream, A, lda, n, 0, Dinv,
+                       (double*)nullptr, 0, info_dev, (unsigned long long*)nullptr, Lw, n, info_off, bt);
     for (int b = 0; b + 1 < nblk; ++b) {
         const int r = nblk - b - 1;
         const int ntri = r * (r + 1) / 2;
         const int ninv = (Cw != nullptr) ? (b + 1) * r : 0;
         // one launch per step: panel + trailing update of every tile (of A and of the appended identity rows), and
         // the factor + inverse of the next diagonal block by the workgroup that has just finished it
-        hipLaunchKernelGGL(chol_step_kernel, dim3((unsigned)(ntri + ninv)), dim3(256), 0, c->stream, A, lda, Lw, n,
-                           Dinv + (size_t)(b & 1) * NB * NB, n, b, Dinv + (size_t)((b + 1) & 1) * NB * NB, info_dev, info_off,
-                           ntri, Cw, n, Linv, ldi, 0);
+        hipLaunchKernelGGL(chol_step_kernel, dim3((unsigned)(ntri + ninv), (unsigned)G), dim3(256), 0, c->stream, A, lda, Lw,
+                           n, Dinv + (size_t)(b & 1) * NB * NB, n, b, Dinv + (size_t)((b + 1) & 1) * NB * NB, info_dev,
+                           info_off, ntri, Cw, n, Linv, ldi, 0, bt);
     }
     if (Cw != nullptr)                                // block column nblk - 1 of L^-T: panel products only
-        hipLaunchKernelGGL(chol_step_kernel, dim3((unsigned)nblk), dim3(256), 0, c->stream, A, lda, Lw, n,
+        hipLaunchKernelGGL(chol_step_kernel, dim3((unsigned)nblk, (unsigned)G), dim3(256), 0, c->stream, A, lda, Lw, n,
                            Dinv + (size_t)((nblk - 1) & 1) * NB * NB, n, nblk - 1, (double*)nullptr, info_dev, info_off, 0, Cw,
-                           n, Linv, ldi, 1);
-    dim3 blk(64, 4), grd((n + 63) / 64, (n + 3) / 4);
-    hipLaunchKernelGGL(take_lower_kernel, grd, blk, 0, c->stream, A, lda, Lw, n, n);
+                           n, Linv, ldi, 1, bt);
+    dim3 blk(64, 4), grd((n + 63) / 64, (n + 3) / 4, (unsigned)G);
+    hipLaunchKernelGGL(take_lower_kernel, grd, blk, 0, c->stream, A, lda, Lw, n, n, bt.sA, bt.sL);
     HIP_TRY(hipGetLastError());
     return EDRGP_OK;
+}
+
+// `batch` independent n x n matrices (stride strideA) factored and inverted in the SAME launches: the steps are
+// latency-bound chains that leave the chip almost idle, so a batch costs about what one matrix does (BASELINE
+// config 4: the 16 length-scales of a candidate).  n in (64, 3072]; info_dev holds `batch` words.
+int potrf_inv_lower_batched(Ctx* c, double* A, int n, int lda, long long strideA, int* info_dev, double* Linv, int ldi,
+                            long long strideI, int batch) {
+    if (batch < 1 || n <= NB || n > 3072) { set_error("potrf_inv_lower_batched: n must be in (64, 3072]"); return EDRGP_ERR_INVALID; }
+    return potrf_lower_fused(c, A, n, lda, info_dev, true, 0, Linv, ldi, batch, strideA, strideI);
 }
 
 // Cholesky factor and its inverse: A <- L (lower, zeros above), Linv <- L^-1.  n in (64, 3072]: out of the same

@@ -21,7 +21,7 @@ def length_scale_grid(d, n=16):
 
 
 def _sweep_worker(h, close, X, y, Z_rows, projections, n_scales, kind, variance, noise, rank, world_size,
-                  want_gradients, want_gram, lane, lanes):
+                  want_gradients, want_gram, lane, lanes, batch=True):
     """One native context working through its share of the (candidate, scale) pairs."""
     out = []
     base_sent = False
@@ -42,7 +42,21 @@ def _sweep_worker(h, close, X, y, Z_rows, projections, n_scales, kind, variance,
             h.set_data_projected(W, X if not base_sent else None, y if not base_sent else None)
             base_sent = True
             h.set_inducing(np.ascontiguousarray(X[Z_rows] @ W))
-            for g in mine:
+            todo = list(mine)
+            if batch and want_gram and not want_gradients and kind == "RBF" and 64 < len(Z_rows) <= 3072:
+                # the scales of this candidate as ONE batch on the device (edrgp_sweep_scales): squared distances
+                # formed once, every factorisation of the 2 x len(mine) advancing in the same launches
+                bounds, grams, gsums, modes = h.sweep_scales(scales[todo], variance, noise, kind, want_gram=True)
+                left = []
+                for i, g in enumerate(todo):
+                    if modes[i] < 0:                      # needs jitter: the per-unit path below climbs the ladder
+                        left.append(g)
+                        continue
+                    out.append({"candidate": c, "scale": g, "lengthscale": float(scales[g]), "bound": float(bounds[i]),
+                                "gram": grams[i], "gsum": gsums[i], "gram_full": W @ grams[i] @ W.T,
+                                "form": int(modes[i])})
+                todo = left
+            for g in todo:
                 ls = np.full((1, W.shape[1]), scales[g])
                 h.set_kernel([kind], [variance], ls, noise)
                 rec = {"candidate": c, "scale": g, "lengthscale": float(scales[g])}
@@ -66,7 +80,7 @@ def _sweep_worker(h, close, X, y, Z_rows, projections, n_scales, kind, variance,
 
 def projection_sweep(X, y, Z_rows, projections, n_scales=16, kind="RBF", variance=1.0, noise=0.01,
                      rank=0, world_size=1, device=None, want_gradients=False, hip=None, want_gram=False,
-                     concurrency=1, hips=None):
+                     concurrency=1, hips=None, batch=True):
     """Evaluate the Titsias bound (and optionally the posterior-mean gradients at the
     training rows) for every (projection, length-scale) pair owned by this rank.
 
@@ -77,6 +91,11 @@ def projection_sweep(X, y, Z_rows, projections, n_scales=16, kind="RBF", varianc
     cheap form: the gradients never leave the device -- ``gram`` = grad^T grad (d_c, d_c),
     ``gsum`` (d_c,) and the back-projected ``gram_full`` = W gram W^T (D, D), whose leading
     eigenvectors are the EDR directions of that candidate.
+
+    ``batch`` (default): with ``want_gram`` (and without ``want_gradients``) the length-scales a rank owns of one
+    candidate are evaluated as ONE batch on the device (``edrgp_sweep_scales``: the squared distances formed once,
+    all factorisations advancing in the same launches); records then carry ``form`` (1 Gram, 2 stable statistics).
+    ``batch=False`` runs them one by one -- same numbers.
 
     ``concurrency`` > 1: that many native contexts on the same device, each on its own host thread
     and streams, share the pairs.  One evaluation at M = 1024 spends ~40 % of its time in
@@ -90,7 +109,7 @@ def projection_sweep(X, y, Z_rows, projections, n_scales=16, kind="RBF", varianc
         own = hip is None
         h = HipGP(dev) if own else hip
         out = _sweep_worker(h, own, X, y, Z_rows, projections, n_scales, kind, variance, noise, rank, world_size,
-                            want_gradients, want_gram, 0, 1)
+                            want_gradients, want_gram, 0, 1, batch)
     else:
         from concurrent.futures import ThreadPoolExecutor
         if hips is not None:                      # caller-owned contexts (one per lane), kept open
@@ -101,7 +120,7 @@ def projection_sweep(X, y, Z_rows, projections, n_scales=16, kind="RBF", varianc
                               for i in range(lanes)], False
         with ThreadPoolExecutor(max_workers=lanes) as ex:
             futs = [ex.submit(_sweep_worker, ctxs[i], not borrowed and not (i == 0 and hip is not None), X, y, Z_rows, projections, n_scales,
-                              kind, variance, noise, rank, world_size, want_gradients, want_gram, i, lanes)
+                              kind, variance, noise, rank, world_size, want_gradients, want_gram, i, lanes, batch)
                     for i in range(lanes)]
             out = [r for f in futs for r in f.result()]
     out.sort(key=lambda r: (r["candidate"], r["scale"]))

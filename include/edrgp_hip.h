@@ -166,6 +166,18 @@ int  edrgp_predict_train(edrgp_ctx* ctx, double* mean, double* grad);
  * gradient matrix stays in HBM. */
 int  edrgp_predict_train_gram(edrgp_ctx* ctx, double* mean, double* gram, double* gsum);
 
+/* BASELINE config 4 as a batch: for the resident training rows (edrgp_set_data / edrgp_set_data_projected) and
+ * inducing inputs, the unit of work of the EDR loop at fixed hyper-parameters (edrgp/base.py:460-461: fit on the
+ * projected rows, posterior-mean gradients at the training rows) for `nscales` isotropic RBF length-scales at one
+ * variance / noise: bounds[nscales] (Titsias bound), grams[nscales * D * D] (J^T J of the mean Jacobian at the
+ * training rows; may be NULL), gsums[nscales * D] (column sums of J; may be NULL), modes[nscales] (1 Gram form,
+ * 2 stable form, -1: this scale needs jitchol jitter -- its bound is NaN and the caller evaluates it with
+ * edrgp_set_kernel + edrgp_sparse_posterior + edrgp_predict_train_gram, which give the same numbers as the batch does
+ * for the others).  The squared distances are formed once, the factorisations of all scales advance in the same
+ * launches.  Needs 64 < M <= 3072, one row chunk, no communicator. */
+int  edrgp_sweep_scales(edrgp_ctx* ctx, int nscales, const double* lengthscales, double variance, double noise_var,
+                        int kind, double* bounds, double* grams, double* gsums, int* modes);
+
 /* debug / parity accessor */
 int  edrgp_get(edrgp_ctx* ctx, int which, double* buf, int64_t cap_elems);
 

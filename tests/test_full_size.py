@@ -168,3 +168,53 @@ def test_c5_full_size_fp32_row_pass(hip):
     assert abs(dvar32[0] - dvar64[0]) <= 1e-2 * abs(dvar64[0])
     assert np.abs(dlen32 - dlen64).max() <= 1e-2 * np.abs(dlen64).max()
     assert np.abs(dZ32 - dZ64).max() <= 0.15 * np.abs(dZ64).max()
+
+
+@pytest.mark.parametrize("dc", [64, 32])
+def test_c4_full_size_batched_sweep(hip, dc):
+    """BASELINE config 4 at its real size (N = 200 000, M = 1024, D = 64; candidate of dimension d_c): the 16
+    length-scales of a candidate as one batch (edrgp_sweep_scales) against (i) the per-unit path on four of them --
+    the two narrowest (Gram form) and the two widest (stable form) -- and (ii) the oracle's bound for one scale of
+    each form; plus a property of the batch itself: every gradient Gram matrix is symmetric positive semi-definite
+    and its trace falls as the length-scale grows past the data scale."""
+    import time
+    from oracle import gp_oracle as go
+    from edrgp_amd.sweep import length_scale_grid, projection_sweep
+    N, M, D = 200000, 1024, 64
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((N, D))
+    y = np.tanh(X @ (np.ones(D) / np.sqrt(D))) + 0.05 * rng.standard_normal(N)
+    y = (y - y.mean()) / y.std()
+    Zr = rng.permutation(N)[:M]
+    W = np.linalg.qr(rng.standard_normal((D, dc)))[0]
+    projection_sweep(X, y, Zr, [W], n_scales=2, want_gram=True, hip=hip)          # base rows resident, warm
+    t0 = time.perf_counter()
+    bat = projection_sweep(X, y, Zr, [W], n_scales=16, want_gram=True, hip=hip)
+    dt = time.perf_counter() - t0
+    assert len(bat) == 16 and all("form" in r for r in bat)
+    print("\nC4 d_c=%d: %.2f ms per unit batched (%d Gram-form, %d stable-form scales)"
+          % (dc, dt * 1e3 / 16, sum(r["form"] == 1 for r in bat), sum(r["form"] == 2 for r in bat)))
+    for r in bat:
+        G = r["gram"]
+        assert np.array_equal(G, G.T) or np.abs(G - G.T).max() <= 1e-12 * np.abs(G).max()
+        assert np.linalg.eigvalsh(0.5 * (G + G.T)).min() >= -1e-9 * np.abs(G).max()
+    tr = [np.trace(r["gram"]) for r in bat]
+    assert tr[-1] < tr[len(tr) // 2]
+    # (i) per-unit path on the extreme scales
+    scales = length_scale_grid(dc, 16)
+    Xp = np.ascontiguousarray(X @ W)
+    hip.set_data(Xp, y)
+    hip.set_inducing(np.ascontiguousarray(Xp[Zr]))
+    for g in (0, 1, 14, 15):
+        hip.set_kernel(["RBF"], [1.0], np.full((1, dc), scales[g]), 0.01)
+        ref = hip.sparse_posterior()
+        _, gram, gsum = hip.predict_train_gram()
+        form = int(hip.get("MODE", (1,))[0])
+        assert form == bat[g]["form"], (g, form, bat[g]["form"])
+        assert abs(bat[g]["bound"] - ref) <= 1e-10 * abs(ref), (g, bat[g]["bound"], ref)
+        assert np.abs(bat[g]["gram"] - gram).max() <= 1e-8 * np.abs(gram).max()
+    # (ii) the oracle's bound for one scale of each form
+    for g in (next(i for i, r in enumerate(bat) if r["form"] == 1), next(i for i, r in enumerate(bat) if r["form"] == 2)):
+        kern = go.make_kernel(["RBF"], dc, [dict(variance=1.0, lengthscale=scales[g])])
+        ref = float(go.vardtc_inference(kern, Xp, Xp[Zr], 0.01, y[:, None])["log_marginal"][0, 0])
+        assert abs(bat[g]["bound"] - ref) <= 1e-10 * abs(ref), (g, bat[g]["bound"], ref)

@@ -90,3 +90,39 @@ def test_sweep_concurrent_contexts_match_sequential(hip):
     for a, b in zip(seq, par):
         assert a["bound"] == b["bound"]
         assert np.array_equal(a["gram"], b["gram"])
+
+
+@pytest.mark.parametrize("N,D,M,dcs", [(3000, 12, 96, (12, 7)), (5000, 10, 300, (10,))])
+def test_sweep_batched_scales_equal_per_unit_path(hip, N, D, M, dcs):
+    """edrgp_sweep_scales (all length-scales of a candidate as one batch: distances formed once, batched
+    factorisations) gives the numbers of the per-unit path -- bound 1e-10, gradient Gram matrix 1e-8 -- and of the
+    oracle; the grid spans both statistics forms (wide length-scales take the stable one)."""
+    from edrgp_amd.sweep import projection_sweep
+    rng = np.random.default_rng(21)
+    X = rng.standard_normal((N, D))
+    y = np.tanh(X[:, 0] + 0.3 * X[:, 2]) + 0.05 * rng.standard_normal(N)
+    y = (y - y.mean()) / y.std()
+    projections = [np.linalg.qr(rng.standard_normal((D, dc)))[0] for dc in dcs]
+    Zrows = rng.permutation(N)[:M]
+    bat = projection_sweep(X, y, Zrows, projections, n_scales=8, want_gram=True, hip=hip)
+    seq = projection_sweep(X, y, Zrows, projections, n_scales=8, want_gram=True, hip=hip, batch=False)
+    assert [(r["candidate"], r["scale"]) for r in bat] == [(r["candidate"], r["scale"]) for r in seq]
+    forms = set()
+    for a, b in zip(bat, seq):
+        forms.add(a.get("form"))
+        assert abs(a["bound"] - b["bound"]) <= 1e-10 * max(abs(b["bound"]), float(N)), (a["candidate"], a["scale"])
+        assert np.abs(a["gram"] - b["gram"]).max() <= 1e-8 * np.abs(b["gram"]).max()
+        assert np.abs(a["gsum"] - b["gsum"]).max() <= 1e-8 * max(np.abs(b["gsum"]).max(), np.sqrt(np.abs(b["gram"]).max()))
+    assert forms >= {1, 2}                 # both statistics forms occurred in the batch
+    # and against the oracle for two of the records (one per form)
+    for form in (1, 2):
+        rec = next(r for r in bat if r.get("form") == form)
+        W = projections[rec["candidate"]]
+        Xp = X @ W
+        kern = go.make_kernel(["RBF"], Xp.shape[1], [dict(variance=1.0, lengthscale=rec["lengthscale"])])
+        inf = go.vardtc_inference(kern, Xp, Xp[Zrows], 0.01, y[:, None])
+        ref = inf["log_marginal"][0, 0]
+        assert abs(rec["bound"] - ref) <= 1e-9 * max(abs(ref), float(N))
+        jac = go.predictive_gradients_mean(kern, Xp, Xp[Zrows], inf["woodbury_vector"])[:, :, 0]
+        G = jac.T @ jac
+        assert np.abs(rec["gram"] - G).max() <= 1e-6 * np.abs(G).max()

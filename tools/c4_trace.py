@@ -15,16 +15,22 @@ X = rng.standard_normal((N, D)); y = np.tanh(X @ (np.ones(D) / np.sqrt(D))) + 0.
 y = (y - y.mean()) / y.std()
 Zr = rng.permutation(N)[:M]
 h = HipGP(0)
+batch = True
 for kv in sys.argv[3:]:
     k, v = kv.split("=")
-    h.set_option(k, float(v))
+    if k == "batch":
+        batch = bool(int(v))
+    else:
+        h.set_option(k, float(v))
 W0 = np.linalg.qr(rng.standard_normal((D, dc)))[0]
 W1 = np.linalg.qr(rng.standard_normal((D, dc)))[0]
-projection_sweep(X, y, Zr, [W0], n_scales=2, want_gram=True, hip=h)           # uploads the base rows, warms up
+projection_sweep(X, y, Zr, [W0], n_scales=ns, want_gram=True, hip=h, batch=batch)           # uploads the base rows, warms up
 h.sync()
 t0 = time.perf_counter()
-out = projection_sweep(X, y, Zr, [W1], n_scales=ns, want_gram=True, hip=h)
+out = projection_sweep(X, y, Zr, [W1], n_scales=ns, want_gram=True, hip=h, batch=batch)
 dt = time.perf_counter() - t0
 modes = h.get("MODE", (4,))
-print("C4 d_c=%d: %.2f ms per (bound + posterior + gradient Gram) unit over %d length-scales; last mode %s" % (dc, dt * 1e3 / ns, ns, modes))
+forms = [r.get("form") for r in out]
+print("C4 d_c=%d batch=%d: %.2f ms per (bound + posterior + gradient Gram) unit over %d length-scales; forms %s"
+      % (dc, batch, dt * 1e3 / ns, ns, forms if batch else modes))
 h.close()
