@@ -261,6 +261,7 @@ def main():
     grad_ms, grad_n = h.profile_get("GRADGEMM")
     kb_ms, kb_n = h.profile_get("KBUILD")
     small_ms, _ = h.profile_get("SMALL")
+    chol_ms, chol_n = h.profile_get("CHOL")
     h.set_option("profile", 0)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -334,8 +335,21 @@ def main():
                                  "kernel alone (its slab reduction included)",
                          "isolated_ms": iso_ms,
                          "isolated_tflops": (flops_per_launch / (iso_ms * 1e-3) * 1e-12) if iso_ms else None},
+            # HIP events around the kernel families inside the timed region.  syrk and grad_gemm have the GPU to
+            # themselves; kernel_build and small_MxM include work queued on the side stream BESIDE other kernels (the
+            # Kmm factorisation runs beside the K_nm build, the Kmm gradient term beside the gradient contraction), so
+            # their event spans include waiting for workgroup slots and the four do not add up to ms_per_step
             "device_ms_per_step": {"syrk": syrk_ms / args.steps, "grad_gemm": grad_ms / args.steps,
-                                   "kernel_build": kb_ms / args.steps, "small_MxM": small_ms / args.steps},
+                                   "kernel_build": kb_ms / args.steps, "small_MxM": small_ms / args.steps,
+                                   "note": "side-stream spans include queueing; not additive"},
+            # the latency-bound kernel family: factorisation + explicit inverse of one M x M matrix out of the same
+            # launches (one per 64-column step); phase 3's (I + A) runs alone, phase 1's (Kmm) beside the K_nm build
+            "cholesky": {"what": "potrf + inverse of the factor, M x M fp64, %d per evaluation" % 2,
+                         "avg_ms": (chol_ms / chol_n) if chol_n else None, "launches": chol_n,
+                         "flops": 2.0 * M ** 3 / 3.0,
+                         "tflops": (2.0 * M ** 3 / 3.0 / (chol_ms / chol_n * 1e-3) * 1e-12) if chol_n else None,
+                         "frac_of_fp64_mfma_peak": (2.0 * M ** 3 / 3.0 / (chol_ms / chol_n * 1e-3) * 1e-12 / FP64_MFMA_SPEC_TFLOPS)
+                         if chol_n else None},
         }
         if shard_check is not None:
             out["sharding_check"] = shard_check

@@ -20,7 +20,7 @@ MAX_PARTS = 4
 MAX_DIM = 256
 
 GET = dict(MODE=14, PHI=1, BVEC=2, LM=3, LB=4, A=5, WV=6, WINV=7, KMM=8, KNM=9, LMI=10, LBI=11, DLDKMM=12, SCALARS=13)
-PROF = dict(SYRK=0, KBUILD=1, GRADGEMM=2, SMALL=3)
+PROF = dict(SYRK=0, KBUILD=1, GRADGEMM=2, SMALL=3, CHOL=4)
 
 
 class EdrgpError(RuntimeError):

@@ -53,6 +53,20 @@ ProfScope::~ProfScope() {
     c->pending_events.push_back({slot, {e0, e1}});
 }
 
+// Pinned host staging owned by the context: copies to and from it are truly asynchronous (a pageable buffer makes
+// hipMemcpyAsync stage and wait: ~90 us in front of the result copies of every evaluation).
+int Ctx::ensure_pinned(size_t doubles) {
+    if (h_pin != nullptr && h_pin_cap >= doubles) return EDRGP_OK;
+    HIP_TRY(hipStreamSynchronize(stream));                 // nothing in flight may still use the old block
+    if (stream2) HIP_TRY(hipStreamSynchronize(stream2));
+    if (h_pin) (void)hipHostFree(h_pin);
+    h_pin = nullptr;
+    h_pin_cap = 0;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_pin), doubles * sizeof(double), hipHostMallocDefault));
+    h_pin_cap = doubles;
+    return EDRGP_OK;
+}
+
 int Ctx::drain_events() {
     for (auto& pe : pending_events) {
         float ms = 0.f;
@@ -312,6 +326,7 @@ int edrgp_ctx_destroy(edrgp_ctx* ctx) {
     (void)hipEventDestroy(c->ev_fork);
     (void)hipEventDestroy(c->ev_join);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
     (void)hipStreamDestroy(c->stream2);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -466,12 +481,16 @@ int edrgp_set_inducing(edrgp_ctx* ctx, const double* Z, int M) {
     const size_t Mcap = ((size_t)M + 127) / 128 * 128;
     TRY(c->Z.reserve(Mcap * D * sizeof(double)));
     TRY(c->Zt.reserve(Mcap * (2 * D + 1) * sizeof(double)));
+    // Z is a borrowed host pointer: it goes through the context's pinned staging, so the upload is asynchronous and
+    // the call returns without waiting for the device (the optimiser sends Z before every evaluation)
+    const size_t zoff = 64 + (size_t)EDRGP_MAX_PARTS * EDRGP_MAX_DIM;
+    TRY(c->ensure_pinned(zoff + (size_t)M * D));
+    std::memcpy(c->h_pin + zoff, Z, (size_t)M * D * sizeof(double));
     HIP_TRY(hipMemsetAsync(c->Z.d(), 0, Mcap * D * sizeof(double), c->stream));
     HIP_TRY(hipMemsetAsync(c->Zt.d(), 0, Mcap * (2 * D + 1) * sizeof(double), c->stream));
-    HIP_TRY(hipMemcpyAsync(c->Z.d(), Z, (size_t)M * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->Z.d(), c->h_pin + zoff, (size_t)M * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
     c->Z_host.assign(Z, Z + (size_t)M * D);
     TRY(build_xtilde(c, c->Z.d(), M, D, c->Zt.d()));
-    HIP_TRY(hipStreamSynchronize(c->stream));   // Z is a borrowed host pointer
     if (c->M != M) c->phi32_bad = false;
     c->M_work = 0;
     c->knm_train_valid = false;
@@ -507,10 +526,11 @@ int edrgp_set_kernel(edrgp_ctx* ctx, int nparts, const int* kinds, const double*
     c->lens.assign(lengthscales, lengthscales + (size_t)nparts * D);
     c->noise_var = noise_var;
     TRY(c->invl.reserve((size_t)EDRGP_MAX_PARTS * EDRGP_MAX_DIM * sizeof(double)));
-    // synchronous copy: the staging vector dies at return, and kernels queued
-    // earlier on the stream may still read the previous values
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(c->invl.d(), invl.data(), invl.size() * sizeof(double), hipMemcpyHostToDevice));
+    // stream-ordered copy out of pinned staging: kernels queued earlier on the stream still read the previous
+    // values, later ones the new ones; no wait for the device
+    TRY(c->ensure_pinned(64 + (size_t)EDRGP_MAX_PARTS * EDRGP_MAX_DIM));
+    std::memcpy(c->h_pin + 64, invl.data(), invl.size() * sizeof(double));
+    HIP_TRY(hipMemcpyAsync(c->invl.d(), c->h_pin + 64, invl.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     c->have_kernel = true;
     c->have_post = false;
     c->knm_train_valid = false;

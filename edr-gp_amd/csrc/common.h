@@ -310,6 +310,9 @@ struct Ctx {
     std::vector<double> Z_host;       // host copy of the inducing inputs (gradient finishing)
     double* h_stage = nullptr;        // pinned staging of the gradient tables
     size_t h_stage_cap = 0;
+    double* h_pin = nullptr;          // pinned: [0, 64) scalars + info words of an evaluation; then Z / 1/lengthscale staging
+    size_t h_pin_cap = 0;             // doubles
+    int ensure_pinned(size_t doubles);
 
     // comm
     void* comm = nullptr;             // ncclComm_t

@@ -181,11 +181,16 @@ struct SparseEval {
         return EDRGP_OK;
     }
 
-    // device scalars and info words -> host; the one place an evaluation waits for the device
+    // device scalars and info words -> host (through pinned staging: asynchronous copies); the one place an
+    // evaluation waits for the device
     int fetch() {
-        HIP_TRY(hipMemcpyAsync(h_sc, sc, sizeof(h_sc), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(h_info, info, sizeof(h_info), hipMemcpyDeviceToHost, c->stream));
+        static_assert(SC_COUNT + 4 <= 64, "scalar block of the pinned staging");
+        TRY(c->ensure_pinned(64));
+        HIP_TRY(hipMemcpyAsync(c->h_pin, sc, sizeof(h_sc), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->h_pin + SC_COUNT, info, sizeof(h_info), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        std::memcpy(h_sc, c->h_pin, sizeof(h_sc));
+        std::memcpy(h_info, c->h_pin + SC_COUNT, sizeof(h_info));
         return EDRGP_OK;
     }
 
@@ -197,7 +202,10 @@ struct SparseEval {
         TRY(kernel_matrix(c, ks, c->Z.d(), Mr, c->Z.d(), Mr, Lm, M, 1, 1e-8 + jit_amount(lvl, kmm_diag_mean), nullptr,
                           nullptr));
         if (padded) TRY(add_diag(c, Lm + (size_t)Mr * M + Mr, M - Mr, M, 1.0));
-        TRY(potrf_inv_lower(c, Lm, M, M, info + 0, Li, M));
+        {
+            ProfScope pc(c, EDRGP_PROF_CHOL);
+            TRY(potrf_inv_lower(c, Lm, M, M, info + 0, Li, M));
+        }
         TRY(diag_minmax(c, Lm, Mr, M, sc + SC_DIAGMIN));
         return EDRGP_OK;
     }
@@ -340,7 +348,10 @@ struct SparseEval {
         HIP_TRY(hipMemcpyAsync(LB, A, (size_t)M * M * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         // jitter on B: mean(diag(B)) = 1 + trA / M, trA known from the failed pass
         TRY(add_diag(c, LB, M, M, bjit));
-        TRY(potrf_inv_lower(c, LB, M, M, info + 1, LBi, M));
+        {
+            ProfScope pc(c, EDRGP_PROF_CHOL);
+            TRY(potrf_inv_lower(c, LB, M, M, info + 1, LBi, M));
+        }
         TRY(sum_log_diag(c, LB, M, M, sc + SC_SUMLOGLB));
         // c = beta LBi v ; u = LBi^T c ; wv = Li^T u     (v = Lm^-1 K_mn y)
         TRY(gemv_n(c, M, M, beta, LBi, M, v_v, v_c));
@@ -659,10 +670,14 @@ struct SparseEval {
         *rows_done = false;
         const bool can_prebuild = c->overlap && nchunks == 1 && !f32 && c->prebuild;
         const bool beside_rows = ((c->overlap == 2) || (c->overlap == 3 && !need_grad && !can_prebuild)) && !assume_stable;
+        // Z and the hyper-parameters reach the device by asynchronous copies on the main stream
+        // (edrgp_set_inducing / edrgp_set_kernel do not wait): the side stream starts behind them
+        HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
         if (beside_rows) {
             TRY(phase2(false));
             *rows_done = true;
             SideStream side(c);
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_fork, 0));
             int st = phase1(careful);
             if (st == EDRGP_OK) st = side.join_into_main();
             return st;
@@ -684,6 +699,7 @@ struct SparseEval {
             }
             prebuilt = true;
             SideStream side(c);
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_fork, 0));
             int st = phase1(careful);
             if (st == EDRGP_OK) st = side.join_into_main();
             return st;

@@ -72,6 +72,7 @@ typedef struct edrgp_ctx edrgp_ctx;
 #define EDRGP_PROF_KBUILD    1   /* K_nm tile build */
 #define EDRGP_PROF_GRADGEMM  2   /* W = K_nm S (gradient contraction) */
 #define EDRGP_PROF_SMALL     3   /* O(M^3) part: Cholesky, trtri, M x M GEMMs */
+#define EDRGP_PROF_CHOL      4   /* factorisation + inverse of one M x M matrix (Kmm, or I + A): 2 M^3 / 3 flop */
 #define EDRGP_PROF_NSLOTS    8
 
 const char* edrgp_last_error(void);
