@@ -366,6 +366,7 @@ int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
     else if (!std::strcmp(key, "kbuild_pad")) c->kbuild_pad = std::max(0, std::min(65536, (int)value));
     else if (!std::strcmp(key, "rbf_epilogue")) c->rbf_epilogue = (value != 0.0);
     else if (!std::strcmp(key, "chol_fused")) c->chol_fused = (value != 0.0);
+    else if (!std::strcmp(key, "chol_cap_grid")) c->chol_cap_grid = (value != 0.0);
     else if (!std::strcmp(key, "chol_inv_fused")) c->chol_inv_fused = (value != 0.0);
     else if (!std::strcmp(key, "chol_rhs")) c->chol_rhs = (value != 0.0);
     else if (!std::strcmp(key, "pad_inducing")) c->pad_inducing = (value != 0.0);

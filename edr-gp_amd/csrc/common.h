@@ -239,6 +239,8 @@ struct Ctx {
     int M_work = 0;                   // working size of the last sparse evaluation (>= M)
     bool chol_rhs = true;             // bound-only evaluations: L_B^-1 (beta v) as an extra row of the factorisation, no explicit L_B^-1
     bool chol_fused = true;           // Cholesky: panel + trailing update in one launch per step (la_chol.hip)
+    bool chol_cap_grid = true;        // a step launch never has more workgroups than CUs (la_chol.hip)
+    bool chol_shares_gpu = false;     // set while a factorisation runs beside another kernel (phase 1 beside the K_nm build)
     bool chol_inv_fused = true;       // ... and the inverse of the factor out of the same launches
     bool rbf_epilogue = true;         // RBF: fused gradient epilogue takes h(r) = -k(r) from the resident K_nm
     bool fuse_grad = true;            // fused Q .* h epilogue of the gradient contraction (single-part kernels, D <= 32)

@@ -474,19 +474,20 @@ __global__ void scale_rows_neg_kernel(const double* __restrict__ Pt, const doubl
     if (i < Mp * Wd) out[i] = -wv[i / Wd] * Pt[i];
 }
 
-// out[m][q] = -wv[m] Z[m][q] (q < D), zero padding up to ldz
+// out[m][q] = -wv[m] Z[m][q] (q < D), zero padding up to ldz; with_wv: column D carries wv[m] itself, so that the
+// product K out also yields K wv (the posterior mean = - sum_m G) in its column D
 __global__ void scale_z_neg_kernel(const double* __restrict__ Z, const double* __restrict__ wv, int Mp, int D, int ldz,
-                                   double* __restrict__ out) {
+                                   double* __restrict__ out, int with_wv) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Mp * ldz) return;
     const int m = i / ldz, q = i - m * ldz;
-    out[i] = (q < D) ? -wv[m] * Z[(size_t)m * D + q] : 0.0;
+    out[i] = (q < D) ? -wv[m] * Z[(size_t)m * D + q] : ((with_wv && q == D) ? wv[m] : 0.0);
 }
 
 // RBF: jac[n][q] = invl[q]^2 (GZ[n][q] ... ) with G = -K diag(wv):  sum_m G = -(K wv)[n]
 //   jac[n][q] = invl[q]^2 * (-x[n][q] * kwv[n] - GZ[n][q]),  GZ = K (-diag(wv) Z)   (rows x ldz)
 __global__ void jac_finish_rbf_kernel(const double* __restrict__ Xs, const double* __restrict__ GZ,
-                                      const double* __restrict__ kwv, int64_t rows, int D, int ldz,
+                                      const double* __restrict__ kwv, int64_t kwv_stride, int64_t rows, int D, int ldz,
                                       const double* __restrict__ invl, double* __restrict__ jac) {
     const int64_t total = rows * D;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -494,7 +495,7 @@ __global__ void jac_finish_rbf_kernel(const double* __restrict__ Xs, const doubl
         const int64_t n = i / D;
         const int q = (int)(i - n * D);
         const double il = invl[q];
-        jac[i] = il * il * (-(Xs[i] * kwv[n]) - GZ[n * ldz + q]);
+        jac[i] = il * il * (-(Xs[i] * kwv[n * kwv_stride]) - GZ[n * ldz + q]);
     }
 }
 
@@ -525,21 +526,29 @@ int predict_chunk(Ctx* c, const KSpec& ks, const double* Xs, int64_t rows, const
                 // posterior mean: one rows x D x Mp product on an even leading dimension instead of
                 // rows x (2D+1) x Mp on an odd one (a second, one-column tile and the guarded loaders: C4,
                 // d = 64: 2.3 -> 0.5 ms).
-                const int ldz = D + (D & 1);
+                // When the mean itself is not asked for and one more column still fits the 64-wide column tile,
+                // wv rides along as column D of the right operand: K wv comes out of the same pass over K instead of
+                // a second one (a rows x Mp gemv: 1.6 GB at Cm).
+                const bool ride = (mean == nullptr) && (D + 2 <= 64);
+                const int ldz = ride ? (D + 2 - (D & 1)) : D + (D & 1);       // even leading dimension
                 TRY(c->ptw.reserve((size_t)Mp * ldz * sizeof(double)));
                 hipLaunchKernelGGL(scale_z_neg_kernel, dim3((Mp * ldz + 255) / 256), dim3(256), 0, c->stream, P, wv, Mp, D,
-                                   ldz, c->ptw.d());
+                                   ldz, c->ptw.d(), ride ? 1 : 0);
                 TRY(gemm(c, false, false, (int)rows, ldz, Mp, 1.0, Kbuf, Mp, c->ptw.d(), ldz, 0.0, GT, ldz));
                 const double* kwv = mean;
-                if (kwv == nullptr) {
+                int64_t kwv_stride = 1;
+                if (ride) {
+                    kwv = GT + D;
+                    kwv_stride = ldz;
+                } else if (kwv == nullptr) {
                     double* tmp = GT + (size_t)rows * ldz;          // GT holds rows x (2D+1) >= rows x (ldz + 1)
                     TRY(gemv_n(c, (int)rows, Mp, 1.0, Kbuf, Mp, wv, tmp));
                     kwv = tmp;
                 }
                 const int64_t total = rows * D;
                 const int nb = (int)std::min<int64_t>(4096, (total + 255) / 256);
-                hipLaunchKernelGGL(jac_finish_rbf_kernel, dim3(std::max(nb, 1)), dim3(256), 0, c->stream, Xs, GT, kwv, rows,
-                                   D, ldz, ks.invl, jac);
+                hipLaunchKernelGGL(jac_finish_rbf_kernel, dim3(std::max(nb, 1)), dim3(256), 0, c->stream, Xs, GT, kwv,
+                                   kwv_stride, rows, D, ldz, ks.invl, jac);
                 continue;
             } else {
                 TRY(hmatrix(c, ks, p, Xs, rows, P, Mp, wv, Gbuf, Mp));

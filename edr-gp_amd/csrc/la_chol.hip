@@ -341,12 +341,13 @@ __global__ void fill_kernel(double* __restrict__ A, size_t count, double v) {
 // steps of the Kmm factorisation (high-priority side stream) get workgroup slots while the build streams beside them;
 // with two tile images (67.6 KB) a step waited for two build workgroups of one CU to retire together, and the first
 // two steps of phase 1 took 494 + 164 us instead of 2 x 38.
-__global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ A, int lda, double* __restrict__ Lout,
+template <bool CAPPED>
+__global__ __launch_bounds__(256, CAPPED ? 1 : 2) void chol_step_kernel(double* __restrict__ A, int lda, double* __restrict__ Lout,
                                                            int ldl, const double* __restrict__ Dinv, int n, int k,
                                                            double* __restrict__ Dinv_next, int* __restrict__ info,
                                                            int info_off, int ntri, double* __restrict__ Cw, int ldc,
                                                            double* __restrict__ Linv, int ldi, int panel_only,
-                                                           CholBatch bt) {
+                                                           CholBatch bt, int ntiles) {
     constexpr int LS = NB + 2;
     constexpr int LDS_DOUBLES = (NB * LS > DIAG_LDS) ? NB * LS : DIAG_LDS;
     __shared__ __attribute__((aligned(16))) double Rbuf[LDS_DOUBLES];
@@ -363,16 +364,25 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ 
     double* R = Rbuf;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lq = lane >> 4;
-    const bool inv_tile = ((int)blockIdx.x >= ntri);
+
+    // A launch never has more workgroups than CUs (the host caps the grid): a step took 37 us instead of 28 as soon
+    // as its tiles outnumbered the CUs and workgroup 0 -- the critical path: its tile, then the factorisation and
+    // inverse of the next diagonal block -- had to share its CU.  The surplus tiles are walked by the workgroups
+    // other than 0 (each ~6 us against workgroup 0's ~25).
+    const int G = (int)gridDim.x;
+    d4 Cij[2][2];                        // the tile being updated (workgroup 0 keeps it for the diagonal-block body)
+    bool next_diag = false;
+    for (int tile = (int)blockIdx.x; tile < ntiles;) {
+    const bool inv_tile = (tile >= ntri);
     int ti, tj;
     if (!inv_tile) {
-        const int t = blockIdx.x;
+        const int t = tile;
         ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
         while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
         while (ti * (ti + 1) / 2 > t) --ti;
         tj = t - ti * (ti + 1) / 2;
     } else {
-        const int u = (int)blockIdx.x - ntri;
+        const int u = tile - ntri;
         ti = u % (k + 1);                // block row of C
         tj = u / (k + 1);                // trailing column (0 when panel_only)
     }
@@ -396,7 +406,6 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ 
 
     // every global operand is requested up front: the tile being updated (used in the epilogue) and both panel
     // tiles (thread -> rows tid/32 + 8 v, columns 2 (tid % 32), 16-byte loads); the second one waits in registers
-    d4 Cij[2][2];
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -521,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ 
 #pragma unroll
             for (int y = 0; y < 2; ++y) S[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[st][x], b[y], S[x][y], 0, 0, 0);
     }
-    const bool next_diag = (Dinv_next != nullptr && blockIdx.x == 0);
+    next_diag = (Dinv_next != nullptr && tile == 0);
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -532,13 +541,18 @@ __global__ __launch_bounds__(256, 2) void chol_step_kernel(double* __restrict__ 
                 Cij[x][y][r] -= S[x][y][r];
                 if (!next_diag && row < n && col < n) Ct[(size_t)row * ldp + col] = Cij[x][y][r];
             }
+    // next tile of this workgroup (workgroup 0 has none; an uncapped launch has one tile per workgroup)
+    if (!CAPPED || blockIdx.x == 0) break;
+    tile = (tile < G) ? G + ((int)blockIdx.x - 1) : tile + (G - 1);
+    __syncthreads();                     // the LDS image is reused
+    }   // tile loop
     // The workgroup of tile (k+1, k+1) has just produced the next diagonal block: it factors and inverts it on the
     // spot, straight out of its registers (no round trip through memory: the work matrix never needs this tile
     // again), so the next step needs no separate diagonal-block launch on the critical path.
     if (next_diag) {
         __syncthreads();                 // every wave is done with the image of L_i
         double (*Lt)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(Rbuf);      // Lt[k][i] = block[i][k], identity padded
-        const int jb = min(NB, n - j0);
+        const int jb = min(NB, n - (k + 1) * NB);
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -611,14 +625,24 @@ static int potrf_lower_fused(Ctx* c, double* A, int n, int lda, int* info_dev, b
         const int ninv = (Cw != nullptr) ? (b + 1) * r : 0;
         // one launch per step: panel + trailing update of every tile (of A and of the appended identity rows), and
         // the factor + inverse of the next diagonal block by the workgroup that has just finished it
-        hipLaunchKernelGGL(chol_step_kernel, dim3((unsigned)(ntri + ninv), (unsigned)G), dim3(256), 0, c->stream, A, lda, Lw,
-                           n, Dinv + (size_t)(b & 1) * NB * NB, n, b, Dinv + (size_t)((b + 1) & 1) * NB * NB, info_dev,
-                           info_off, ntri, Cw, n, Linv, ldi, 0, bt);
+        const int ntiles = ntri + ninv;
+        // one matrix with the GPU to itself: never more workgroups than CUs (see the kernel; in isolation 1094 ->
+        // 1001 us at n = 2048).  A batch fills the chip anyway, and beside the K_nm build the capped variant (one
+        // workgroup per CU by its register budget) finds slots later than the plain one (+0.25 ms per evaluation)
+        const int gx = (G == 1 && c->chol_cap_grid && !c->chol_shares_gpu && ntiles > c->num_cu) ? c->num_cu : ntiles;
+        if (gx < ntiles)
+            hipLaunchKernelGGL(chol_step_kernel<true>, dim3((unsigned)gx, (unsigned)G), dim3(256), 0, c->stream, A, lda, Lw,
+                               n, Dinv + (size_t)(b & 1) * NB * NB, n, b, Dinv + (size_t)((b + 1) & 1) * NB * NB, info_dev,
+                               info_off, ntri, Cw, n, Linv, ldi, 0, bt, ntiles);
+        else
+            hipLaunchKernelGGL(chol_step_kernel<false>, dim3((unsigned)gx, (unsigned)G), dim3(256), 0, c->stream, A, lda, Lw,
+                               n, Dinv + (size_t)(b & 1) * NB * NB, n, b, Dinv + (size_t)((b + 1) & 1) * NB * NB, info_dev,
+                               info_off, ntri, Cw, n, Linv, ldi, 0, bt, ntiles);
     }
     if (Cw != nullptr)                                // block column nblk - 1 of L^-T: panel products only
-        hipLaunchKernelGGL(chol_step_kernel, dim3((unsigned)nblk, (unsigned)G), dim3(256), 0, c->stream, A, lda, Lw, n,
+        hipLaunchKernelGGL(chol_step_kernel<false>, dim3((unsigned)nblk, (unsigned)G), dim3(256), 0, c->stream, A, lda, Lw, n,
                            Dinv + (size_t)((nblk - 1) & 1) * NB * NB, n, nblk - 1, (double*)nullptr, info_dev, info_off, 0, Cw,
-                           n, Linv, ldi, 1, bt);
+                           n, Linv, ldi, 1, bt, nblk);
     dim3 blk(64, 4), grd((n + 63) / 64, (n + 3) / 4, (unsigned)G);
     hipLaunchKernelGGL(take_lower_kernel, grd, blk, 0, c->stream, A, lda, Lw, n, n, bt.sA, bt.sL);
     HIP_TRY(hipGetLastError());

@@ -678,7 +678,9 @@ struct SparseEval {
             *rows_done = true;
             SideStream side(c);
             HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_fork, 0));
+            c->chol_shares_gpu = true;
             int st = phase1(careful);
+            c->chol_shares_gpu = false;
             if (st == EDRGP_OK) st = side.join_into_main();
             return st;
         }
@@ -700,7 +702,9 @@ struct SparseEval {
             prebuilt = true;
             SideStream side(c);
             HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_fork, 0));
+            c->chol_shares_gpu = true;
             int st = phase1(careful);
+            c->chol_shares_gpu = false;
             if (st == EDRGP_OK) st = side.join_into_main();
             return st;
         }
