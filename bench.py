@@ -202,6 +202,9 @@ def main():
     ap.add_argument("--iters", type=int, default=ITERS_PER_FIT)
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 = skip the CPU baseline leg (oracle on the host cores)")
     ap.add_argument("--check-sharding", action="store_true", help="run the sharded-vs-whole check (always on for --gpus > 1)")
+    ap.add_argument("--host-allreduce", action="store_true",
+                    help="rehearsal of the N > 1 path on ONE device: every rank on GPU 0, torch.distributed on gloo, the "
+                         "library's exchange through edrgp_comm_init_host (never what the driver measures)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -214,7 +217,12 @@ def main():
 
     import torch
     dist = None
-    if world > 1:
+    rehearsal = args.host_allreduce and world > 1
+    if rehearsal:
+        import torch.distributed as dist
+        local_rank = 0
+        dist.init_process_group(backend="gloo")
+    elif world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -225,7 +233,9 @@ def main():
     # run for the same state (as GPy's inference does); the benchmark step does NOT use that shortcut: its
     # "posterior build" is a full evaluation, nothing in the timed region is taken from a cache.
     h.set_option("posterior_reuse", 0)
-    if world > 1:
+    if rehearsal:
+        h.comm_init_host(world, rank, lambda a: dist.all_reduce(torch.from_numpy(a), op=dist.ReduceOp.SUM))
+    elif world > 1:
         box = [HipGP.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         h.comm_init(world, rank, box[0])
@@ -263,8 +273,9 @@ def main():
     small_ms, _ = h.profile_get("SMALL")
     chol_ms, chol_n = h.profile_get("CHOL")
     h.set_option("profile", 0)
+    red_dev = "cpu" if rehearsal else "cuda"
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -281,7 +292,7 @@ def main():
     barrier_sync()
     lml_elapsed = time.perf_counter() - t1
     if dist is not None:
-        t = torch.tensor([lml_elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([lml_elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         lml_elapsed = float(t.item())
     mode = int(h.get("MODE", (1,))[0])
@@ -320,8 +331,9 @@ def main():
                                    "step = %d bound+gradient evaluations + posterior + predict/predict_gradient on N rows"
                                    % (N, M, D, args.kind, args.iters),
                        "N_per_gpu": N, "M": M, "D": D, "kernel": args.kind, "evals_per_step": args.iters,
-                       "sharding": "rows; one RCCL sum-all-reduce of Phi|K_mn y and of gradient partials per evaluation"
-                       if world > 1 else "single GPU", "stats_form": {1: "gram", 2: "stable"}.get(mode, "?")},
+                       "sharding": ("REHEARSAL on one device, exchange over gloo: not a measurement" if rehearsal else
+                                    "rows; one RCCL sum-all-reduce of the packed lower triangle of Phi | K_mn y and of the "
+                                    "gradient partials per evaluation") if world > 1 else "single GPU", "stats_form": {1: "gram", 2: "stable"}.get(mode, "?")},
             "lml_evals_per_sec": n_lml / lml_elapsed,
             "lml_grad_evals_per_sec": args.steps * args.iters / elapsed,
             "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel<128,128,true,true,1> (Phi = K_mn K_nm, fp64 MFMA syrk)",
