@@ -66,6 +66,13 @@ PROTOTYPES = {
     "edrgp_predict_grad": [_ctx_p, _c_double_p, ctypes.c_int64, _c_double_p],
     "edrgp_predict_train": [_ctx_p, _c_double_p, _c_double_p],
     "edrgp_predict_train_gram": [_ctx_p, _c_double_p, _c_double_p, _c_double_p],
+    "edrgp_ep_begin": [_ctx_p, _c_double_p],
+    "edrgp_ep_sweep": [_ctx_p, _c_int_p, ctypes.c_double, ctypes.c_double, _c_double_p, _c_double_p],
+    "edrgp_ep_finish": [_ctx_p, _c_double_p],
+    "edrgp_ep_get_sites": [_ctx_p, _c_double_p, _c_double_p],
+    "edrgp_ep_set_sites": [_ctx_p, _c_double_p, _c_double_p, ctypes.c_double],
+    "edrgp_ep_lml_grad": [_ctx_p, _c_double_p, _c_double_p, _c_double_p],
+    "edrgp_ep_posterior": [_ctx_p, _c_double_p],
     "edrgp_sweep_scales": [_ctx_p, ctypes.c_int, _c_double_p, ctypes.c_double, ctypes.c_double, ctypes.c_int, _c_double_p,
                            _c_double_p, _c_double_p, _c_int_p],
     "edrgp_get": [_ctx_p, ctypes.c_int, _c_double_p, ctypes.c_int64],

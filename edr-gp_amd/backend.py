@@ -165,6 +165,50 @@ class HipGP:
         check(self._lib.edrgp_predict_train_gram(self._ctx, dptr(mean), dptr(gram), dptr(gsum)))
         return mean, gram, gsum
 
+    # -- classification (EP) -----------------------------------------------------
+    def ep_begin(self, y01):
+        y = as_f64(np.ravel(y01))
+        if y.shape[0] != self.N:
+            raise ValueError("labels must have one entry per resident row")
+        check(self._lib.edrgp_ep_begin(self._ctx, dptr(y)))
+
+    def ep_sweep(self, order, eta=1.0, delta=1.0):
+        order = np.ascontiguousarray(order, dtype=np.int32)
+        dt, dv = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        check(self._lib.edrgp_ep_sweep(self._ctx, order.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), float(eta), float(delta),
+                                       ctypes.byref(dt), ctypes.byref(dv)))
+        return dt.value, dv.value
+
+    def ep_finish(self):
+        out = ctypes.c_double(0.0)
+        check(self._lib.edrgp_ep_finish(self._ctx, ctypes.byref(out)))
+        return out.value
+
+    def ep_get_sites(self):
+        tau, v = np.empty(self.N), np.empty(self.N)
+        check(self._lib.edrgp_ep_get_sites(self._ctx, dptr(tau), dptr(v)))
+        return tau, v
+
+    def ep_set_sites(self, tau, v, log_Z_tilde):
+        check(self._lib.edrgp_ep_set_sites(self._ctx, dptr(as_f64(tau)), dptr(as_f64(v)), float(log_Z_tilde)))
+
+    def ep_lml(self):
+        out = ctypes.c_double(0.0)
+        check(self._lib.edrgp_ep_lml_grad(self._ctx, ctypes.byref(out), None, None))
+        return out.value
+
+    def ep_lml_grad(self):
+        lml = ctypes.c_double(0.0)
+        dvar = np.zeros(self.nparts)
+        dlen = np.zeros((self.nparts, self.D))
+        check(self._lib.edrgp_ep_lml_grad(self._ctx, ctypes.byref(lml), dptr(dvar), dptr(dlen)))
+        return lml.value, dvar, dlen
+
+    def ep_posterior(self):
+        out = ctypes.c_double(0.0)
+        check(self._lib.edrgp_ep_posterior(self._ctx, ctypes.byref(out)))
+        return out.value
+
     def sweep_scales(self, lengthscales, variance=1.0, noise_var=0.01, kind="RBF", want_gram=True):
         """Bound (and J^T J / column sums of the mean Jacobian at the training rows) for a grid of isotropic
         length-scales of the resident rows and inducing inputs, as ONE batch on the device.

@@ -100,6 +100,45 @@ struct DenseOut {
     double dnoise = 0.0;
 };
 
+// kern.update_gradients_full(dL_dK, X) for the resident rows: d/dvariance and d/dlengthscale of every additive part
+// from dL/dK (n x n; Tn is an n x n scratch).  Shared by the exact GP and the EP classifier (ep_eval.hip).
+int dense_kernel_gradients(Ctx* c, const double* dK, double* Tn, std::vector<double>* dvar, std::vector<double>* dlen) {
+    const int n = (int)c->N, D = c->D, np = c->nparts, Wd = 2 * D + 1;
+    const KSpec ks = make_kspec(c);
+    double* sc = c->scal.d();
+    HIP_TRY(hipMemsetAsync(sc + SC_DVAR_NM, 0, EDRGP_MAX_PARTS * sizeof(double), c->stream));
+    TRY(c->gt_nm.reserve((size_t)np * n * Wd * sizeof(double)));
+    for (int p = 0; p < np; ++p) {
+        TRY(grad_elementwise(c, ks, p, c->X.d(), nullptr, n, c->X.d(), n, dK, n, 0.0, nullptr, Tn, n,
+                             sc + SC_DVAR_NM + p));
+        TRY(gemm(c, true, false, n, Wd, n, 1.0, Tn, n, c->Xt.d(), Wd, 0.0, c->gt_nm.d() + (size_t)p * n * Wd, Wd));
+    }
+    std::vector<double> g((size_t)np * n * Wd), Xh((size_t)n * D);
+    double h_dv[EDRGP_MAX_PARTS];
+    HIP_TRY(hipMemcpyAsync(h_dv, sc + SC_DVAR_NM, sizeof(h_dv), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(g.data(), c->gt_nm.d(), g.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(Xh.data(), c->X.d(), Xh.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dvar->assign(np, 0.0);
+    dlen->assign((size_t)np * D, 0.0);
+    for (int p = 0; p < np; ++p) {
+        (*dvar)[p] = h_dv[p];
+        const double* G = &g[(size_t)p * n * Wd];
+        for (int q = 0; q < D; ++q) {
+            const double l = c->lens[(size_t)p * D + q];
+            const double il3 = 1.0 / (l * l * l);
+            double s = 0.0;
+            for (int m = 0; m < n; ++m) {
+                const double x = Xh[(size_t)m * D + q];
+                const double* gm = G + (size_t)m * Wd;
+                s += gm[D + 1 + q] + gm[D] * x * x - 2.0 * x * gm[q];
+            }
+            (*dlen)[(size_t)p * D + q] = -il3 * s;
+        }
+    }
+    return EDRGP_OK;
+}
+
 // ExactGaussianInference.inference on the resident (X, y).
 static int dense_eval(Ctx* c, bool need_grad, bool need_post, DenseOut* out) {
     if (!c->have_data || !c->have_kernel) {
@@ -162,34 +201,7 @@ static int dense_eval(Ctx* c, bool need_grad, bool need_post, DenseOut* out) {
     }
     // dL/dK = 1/2 (alpha alpha^T - Ky^-1)
     TRY(combine3(c, n, -0.5, Kyi, 0.0, nullptr, 0.0, nullptr, 0.5, alpha, dK));
-    TRY(c->gt_nm.reserve((size_t)np * n * Wd * sizeof(double)));
-    for (int p = 0; p < np; ++p) {
-        TRY(grad_elementwise(c, ks, p, c->X.d(), nullptr, n, c->X.d(), n, dK, n, 0.0, nullptr, Tn, n,
-                             sc + SC_DVAR_NM + p));
-        TRY(gemm(c, true, false, n, Wd, n, 1.0, Tn, n, c->Xt.d(), Wd, 0.0, c->gt_nm.d() + (size_t)p * n * Wd, Wd));
-    }
-    std::vector<double> g((size_t)np * n * Wd), Xh((size_t)n * D);
-    HIP_TRY(hipMemcpyAsync(h_sc, sc, sizeof(h_sc), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(g.data(), c->gt_nm.d(), g.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(Xh.data(), c->X.d(), Xh.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    out->dvar.assign(np, 0.0);
-    out->dlen.assign((size_t)np * D, 0.0);
-    for (int p = 0; p < np; ++p) {
-        out->dvar[p] = h_sc[SC_DVAR_NM + p];
-        const double* G = &g[(size_t)p * n * Wd];
-        for (int q = 0; q < D; ++q) {
-            const double l = c->lens[(size_t)p * D + q];
-            const double il3 = 1.0 / (l * l * l);
-            double s = 0.0;
-            for (int m = 0; m < n; ++m) {
-                const double x = Xh[(size_t)m * D + q];
-                const double* gm = G + (size_t)m * Wd;
-                s += gm[D + 1 + q] + gm[D] * x * x - 2.0 * x * gm[q];
-            }
-            out->dlen[(size_t)p * D + q] = -il3 * s;
-        }
-    }
+    TRY(dense_kernel_gradients(c, dK, Tn, &out->dvar, &out->dlen));
     out->dnoise = 0.5 * (h_sc[SC_ALPHASQ] - h_sc[SC_TRKYI]);
     return EDRGP_OK;
 }
@@ -411,6 +423,7 @@ int edrgp_set_data(edrgp_ctx* ctx, const double* X, const double* y, int64_t N, 
     c->phi32_bad = false;
     c->glob_valid = false;
     c->knm_train_valid = false;
+    c->ep_begun = c->ep_valid = false;
     TRY(build_xtilde(c, c->X.d(), N, D, c->Xt.d()));
     TRY(build_xq(c, c->X.d(), N, D, c->Xq.d()));
     TRY(sum_sq(c, c->y.d(), N, c->scal.d() + SC_YY));
@@ -630,6 +643,50 @@ int edrgp_predict_train_gram(edrgp_ctx* ctx, double* mean, double* gram, double*
     if (!c->have_data) { set_error("predict_train_gram: no data"); return EDRGP_ERR_STATE; }
     if (!gram) { set_error("predict_train_gram: gram is required"); return EDRGP_ERR_INVALID; }
     return predict_rows(c, c->X.d(), c->N, mean, nullptr, nullptr, gram, gsum);
+}
+
+int edrgp_ep_begin(edrgp_ctx* ctx, const double* y) {
+    CTX(ctx);
+    if (!y) { set_error("ep_begin: labels required"); return EDRGP_ERR_INVALID; }
+    return ep_begin(c, y);
+}
+
+int edrgp_ep_sweep(edrgp_ctx* ctx, const int* order, double eta, double delta, double* tau_diff, double* v_diff) {
+    CTX(ctx);
+    return ep_sweep(c, order, eta, delta, tau_diff, v_diff);
+}
+
+int edrgp_ep_finish(edrgp_ctx* ctx, double* log_Z_tilde) {
+    CTX(ctx);
+    return ep_finish(c, log_Z_tilde);
+}
+
+int edrgp_ep_get_sites(edrgp_ctx* ctx, double* tau, double* v) {
+    CTX(ctx);
+    return ep_sites(c, tau, v, nullptr, nullptr, 0.0);
+}
+
+int edrgp_ep_set_sites(edrgp_ctx* ctx, const double* tau, const double* v, double log_Z_tilde) {
+    CTX(ctx);
+    if (!tau || !v) { set_error("ep_set_sites: tau and v required"); return EDRGP_ERR_INVALID; }
+    return ep_sites(c, nullptr, nullptr, tau, v, log_Z_tilde);
+}
+
+int edrgp_ep_lml_grad(edrgp_ctx* ctx, double* lml, double* dvar, double* dlen) {
+    CTX(ctx);
+    std::vector<double> gv, gl;
+    const bool need_grad = (dvar || dlen);
+    TRY(ep_eval(c, need_grad, false, lml, &gv, &gl));
+    if (need_grad) {
+        if (dvar) std::memcpy(dvar, gv.data(), gv.size() * sizeof(double));
+        if (dlen) std::memcpy(dlen, gl.data(), gl.size() * sizeof(double));
+    }
+    return EDRGP_OK;
+}
+
+int edrgp_ep_posterior(edrgp_ctx* ctx, double* lml) {
+    CTX(ctx);
+    return ep_eval(c, false, true, lml, nullptr, nullptr);
 }
 
 int edrgp_sweep_scales(edrgp_ctx* ctx, int nscales, const double* lengthscales, double variance, double noise_var,

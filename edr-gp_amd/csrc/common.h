@@ -307,6 +307,9 @@ struct Ctx {
     DBuf slabs, bpart, scal, info, gt_nm, gt_mm, tmpvec[6], panel, trtri_ws, dinv, red, lbaug;
     DBuf pack;                        // lower triangle of Phi and b, packed for the all-reduce
     DBuf sw_small, sw_r2, sw_mats, sw_kall;   // batched length-scale sweep (sweep_eval.hip)
+    DBuf ep_K, ep_Sigma, ep_vec;      // EP classifier (ep_eval.hip): K, Sigma (N x N), site / cavity / moment vectors
+    bool ep_begun = false, ep_valid = false;
+    double ep_logZt = 0.0;            // log Z_tilde of the fitted sites
     bool kbuild_r2 = false;           // the MFMA build stores r^2 instead of k(r^2) (set around the sweep's distance pass)
     std::vector<double> host_scal;
     std::vector<double> Z_host;       // host copy of the inducing inputs (gradient finishing)

@@ -109,6 +109,7 @@ inline double var_sum(const Ctx* c) {
 }
 
 int ensure_mats(Ctx* c, int n, int count);
+int dense_kernel_gradients(Ctx* c, const double* dK, double* Tn, std::vector<double>* dvar, std::vector<double>* dlen);
 
 // jitchol's jitter ladder: level -1 = none, level k = mean(diag) * 1e-6 * 10^k
 inline double jit_amount(int level, double diag_mean_) {
@@ -130,5 +131,12 @@ int posterior_from_last_gradient(Ctx* c);
 // [Phi | b] summed over the ranks: the lower triangle and b travel (M (M + 1) / 2 + M values), the upper
 // triangle is restored by mirroring (comm.hip)
 int allreduce_phi(Ctx* c, double* Phi, int M);
+
+// EP classifier (ep_eval.hip)
+int ep_begin(Ctx* c, const double* y_host);
+int ep_sweep(Ctx* c, const int* order, double eta, double delta, double* tau_diff, double* v_diff);
+int ep_finish(Ctx* c, double* log_Z_tilde);
+int ep_sites(Ctx* c, double* tau, double* v, const double* tau_in, const double* v_in, double logZt_in);
+int ep_eval(Ctx* c, bool need_grad, bool need_post, double* lml, std::vector<double>* dvar, std::vector<double>* dlen);
 
 }  // namespace edrgp

@@ -146,11 +146,45 @@ class HipEvaluator:
         lml, dvar, dlen, dnoise = h.dense_lml_grad()
         return lml, dvar, dlen, dnoise, None
 
-    def _ensure_posterior(self, model):
+    def _ensure_sites(self, model):
+        """EP site parameters resident on the device: fitted once per optimize() call (GPy EP, ep_mode "alt"), or
+        restored from the model when another model used the shared context in between."""
         h = self._sync_state(model)
-        key = (self._sent.get("kern"), self._sent.get("Z"))
+        if model._sites is None:
+            h.ep_begin(model.Y[:, 0])
+            sweeps, stop = 0, False
+            while not stop and sweeps < model.ep_max_iters:
+                order = np.random.permutation(model.num_data)          # upstream: a fresh permutation per sweep
+                d_tau, d_v = h.ep_sweep(order, model.ep_eta, model.ep_delta)
+                if sweeps > 0:
+                    stop = (d_tau < model.ep_epsilon) and (d_v < model.ep_epsilon)
+                sweeps += 1
+            log_Z_tilde = h.ep_finish()
+            tau, v = h.ep_get_sites()
+            model._set_sites(tau, v, log_Z_tilde, sweeps)
+            self._sent["sites"] = model._sites_version
+            self._sent.pop("post", None)
+        elif self._sent.get("sites") is not model._sites_version:
+            h.ep_set_sites(*model._sites)
+            self._sent["sites"] = model._sites_version
+            self._sent.pop("post", None)
+        return h
+
+    def ep_lml(self, model):
+        return self._ensure_sites(model).ep_lml()
+
+    def ep_lml_grad(self, model):
+        return self._ensure_sites(model).ep_lml_grad()
+
+    def _ensure_posterior(self, model):
+        classifier = getattr(model, "is_classifier", False)
+        h = self._ensure_sites(model) if classifier else self._sync_state(model)
+        key = (self._sent.get("kern"), self._sent.get("Z"), self._sent.get("sites"))
         if self._sent.get("post") != key:
-            model._lml_cache = h.sparse_posterior() if model.is_sparse else h.dense_posterior()
+            if classifier:
+                model._lml_cache = h.ep_posterior()
+            else:
+                model._lml_cache = h.sparse_posterior() if model.is_sparse else h.dense_posterior()
             self._sent["post"] = key
         return h
 
@@ -487,6 +521,96 @@ class SparseGPRegressionModel(_GPModel):
         return d
 
 
+class GPClassificationModel(_GPModel):
+    """Stands where ``GPy.models.GPClassification`` stands (edrgp/gp_model/classification.py:63-64): Bernoulli
+    likelihood with the probit link, expectation propagation (GPy ``EP``: epsilon 1e-6, eta = delta = 1, sequential
+    site updates in a random order, mode "alt" -- the sites are fitted once at the start of every ``optimize()`` call
+    and held fixed while the kernel hyper-parameters are optimised).  Parameters: the kernel's only (no noise)."""
+    is_classifier = True
+
+    def __init__(self, X, Y, kernel=None, Y_metadata=None, mean_function=None, evaluator=None, device=None):
+        if Y_metadata is not None or mean_function is not None:
+            raise NotImplementedError("Y_metadata / mean_function are GPy-specific and not supported")
+        Y = np.asarray(Y, dtype=np.float64)
+        if not np.all(np.isin(np.unique(Y), (0.0, 1.0))):
+            raise ValueError("GP classification expects labels 0 / 1")
+        super().__init__(X, Y, kernel, 1.0, None, evaluator, device)
+        self.ep_epsilon, self.ep_eta, self.ep_delta, self.ep_max_iters = 1e-6, 1.0, 1.0, 10 ** 6
+        self._sites = None                 # (tau_tilde, v_tilde, log_Z_tilde) of the last EP run
+        self._sites_version = None
+        self.ep_sweeps = 0
+
+    def _set_sites(self, tau, v, log_Z_tilde, sweeps=0):
+        self._sites = (np.array(tau, dtype=np.float64), np.array(v, dtype=np.float64), float(log_Z_tilde))
+        self._sites_version = object()
+        self.ep_sweeps = int(sweeps)
+        self._lml_cache = None
+
+    # -- parameters: kernel only ---------------------------------------------------
+    def _positive_params(self):
+        vals = []
+        for p in self.kern.parts:
+            vals.append(p.variance)
+            vals.extend(p.lengthscale.tolist())
+        return np.array(vals, dtype=np.float64)
+
+    def _set_positive_params(self, vals):
+        i = 0
+        for p in self.kern.parts:
+            p.variance = float(vals[i]); i += 1
+            n = p.lengthscale.size
+            p.lengthscale = np.array(vals[i:i + n], dtype=np.float64); i += n
+        self._lml_cache = None
+
+    def parameter_names(self):
+        return super().parameter_names()[:-1]
+
+    def _log_likelihood_gradients(self):
+        lml, dvar, dlen = self._evaluator.ep_lml_grad(self)
+        self._lml_cache = lml
+        g = []
+        for i, p in enumerate(self.kern.parts):
+            g.append(dvar[i])
+            if p.ARD:
+                g.extend(np.asarray(dlen[i]).tolist())
+            else:
+                g.append(float(np.sum(dlen[i])))
+        return lml, np.zeros(0), np.array(g, dtype=np.float64)
+
+    def _lml(self):
+        if self._lml_cache is None:
+            self._lml_cache = self._evaluator.ep_lml(self)
+        return self._lml_cache
+
+    def log_likelihood(self):
+        return float(self._lml())
+
+    def optimize(self, *args, **kwargs):
+        self._sites = None                 # EP.on_optimization_start: a fresh EP run for this call
+        self._lml_cache = None
+        return super().optimize(*args, **kwargs)
+
+    # -- prediction ------------------------------------------------------------------
+    def predict(self, Xnew, full_cov=False, Y_metadata=None, kern=None, likelihood=None, include_likelihood=True):
+        """GPy GP.predict through the Bernoulli likelihood: (P(y = 1 | x*) = Phi(mu / sqrt(1 + var)) as (n, 1), NaN):
+        the probit link has no closed-form predictive variance upstream either."""
+        from scipy.special import ndtr
+        if full_cov:
+            raise NotImplementedError("full_cov=True is not on the MI355X path")
+        mu, var = self._raw_predict(Xnew)
+        if not include_likelihood:
+            return mu, var
+        return ndtr(mu / np.sqrt(1.0 + var)), np.full_like(mu, np.nan)
+
+    def to_dict(self):
+        d = super().to_dict()
+        d.pop("noise_variance", None)
+        d["noise_variance"] = 0.0
+        if self._sites is not None:
+            d["ep_tau"], d["ep_v"], d["ep_log_Z_tilde"] = self._sites[0], self._sites[1], np.array(self._sites[2])
+        return d
+
+
 def load_model(path, evaluator=None, device=None):
     """Rebuilds a model written by ``pickle`` (an .npz archive: arrays and strings only)."""
     with np.load(path, allow_pickle=False) as f:
@@ -495,6 +619,11 @@ def load_model(path, evaluator=None, device=None):
                                           bool(f["ARD"][i])) for i in range(len(kinds))]
         kernel = parts[0] if len(parts) == 1 else _kern.Add(parts)
         normalizer = bool(f["normalize"])
+        if str(f["model"]) == "GPClassificationModel":
+            m = GPClassificationModel(f["X"], f["Y"], kernel, evaluator=evaluator, device=device)
+            if "ep_tau" in f.files:
+                m._set_sites(f["ep_tau"], f["ep_v"], float(f["ep_log_Z_tilde"]))
+            return m
         if str(f["model"]) == "SparseGPRegressionModel":
             m = SparseGPRegressionModel(f["X"], f["Y"], kernel, Z=f["Z"], normalizer=normalizer,
                                         evaluator=evaluator, device=device,

@@ -167,6 +167,27 @@ int  edrgp_predict_train(edrgp_ctx* ctx, double* mean, double* grad);
  * gradient matrix stays in HBM. */
 int  edrgp_predict_train_gram(edrgp_ctx* ctx, double* mean, double* gram, double* gsum);
 
+/* GP classification: GPy GPClassification = Bernoulli likelihood (probit link) + expectation propagation
+ * (edrgp/gp_model/classification.py:63-64), dense, on the resident training inputs.  GPy's EP in its default
+ * "alt" mode fits the site parameters once per optimize() call and then holds them fixed while the kernel
+ * hyper-parameters move:
+ *   edrgp_ep_begin(labels 0/1)                        K = kern.K(X) for the current hyper-parameters, sites zero
+ *   edrgp_ep_sweep(order[N], eta, delta, &dt, &dv)    one sweep of site updates in the given order (upstream: a random
+ *                                                     permutation per sweep) + recomputation of the posterior; returns
+ *                                                     the mean squared change of tau and v (stop when both < 1e-6)
+ *   edrgp_ep_finish(&log_Z_tilde)                     fixes the sites
+ *   edrgp_ep_lml_grad / edrgp_ep_posterior            EP._inference for the fixed sites and the CURRENT hyper-parameters:
+ *                                                     log marginal, d/dvariance, d/dlengthscale; woodbury vector / inverse
+ *                                                     for edrgp_predict (latent mean / variance) and edrgp_predict_grad
+ *   edrgp_ep_get_sites / edrgp_ep_set_sites           parity accessor / restoring a saved model */
+int  edrgp_ep_begin(edrgp_ctx* ctx, const double* y);
+int  edrgp_ep_sweep(edrgp_ctx* ctx, const int* order, double eta, double delta, double* tau_diff, double* v_diff);
+int  edrgp_ep_finish(edrgp_ctx* ctx, double* log_Z_tilde);
+int  edrgp_ep_get_sites(edrgp_ctx* ctx, double* tau, double* v);
+int  edrgp_ep_set_sites(edrgp_ctx* ctx, const double* tau, const double* v, double log_Z_tilde);
+int  edrgp_ep_lml_grad(edrgp_ctx* ctx, double* lml, double* dvar, double* dlen);
+int  edrgp_ep_posterior(edrgp_ctx* ctx, double* lml);
+
 /* BASELINE config 4 as a batch: for the resident training rows (edrgp_set_data / edrgp_set_data_projected) and
  * inducing inputs, the unit of work of the EDR loop at fixed hyper-parameters (edrgp/base.py:460-461: fit on the
  * projected rows, posterior-mean gradients at the training rows) for `nscales` isotropic RBF length-scales at one

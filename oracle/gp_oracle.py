@@ -427,6 +427,131 @@ def dense_gradients(kern, X, inf):
 
 
 # --------------------------------------------------------------------------
+# GP classification: GPy.models.GPClassification = GP + Bernoulli(probit) + EP
+# (edrgp/gp_model/classification.py:63-64).  Restated: likelihoods/bernoulli.py
+# (moments_match_ep, predictive_mean), util/univariate_Gaussian.py,
+# inference/latent_function_inference/expectation_propagation.py (class EP:
+# epsilon=1e-6, eta=1, delta=1, sequential site updates in a random order, full
+# recomputation of the posterior after every sweep, ep_mode="alt": the sites are
+# fitted ONCE per optimize() call -- on_optimization_start resets them -- and held
+# fixed while the kernel hyper-parameters are optimised).
+# Parity status: unpinned, as for the rest of the GPy surface (GPy is absent); the
+# fixed point is checked by its own consistency conditions in tests/test_classification.py.
+# --------------------------------------------------------------------------
+from scipy import special as _special
+
+_EPS = np.finfo(float).eps
+
+
+def log_cdf_normal(z):
+    return _special.log_ndtr(z)
+
+
+def deriv_log_cdf_normal(z):
+    """phi(z) / Phi(z) (GPy util.univariate_Gaussian.derivLogCdfNormal), stable in the lower tail."""
+    return np.exp(-0.5 * z * z - 0.5 * LOG_2_PI - _special.log_ndtr(z))
+
+
+def bernoulli_moments_match_ep(y, tau_cav, v_cav):
+    """Bernoulli.moments_match_ep with the probit link: zeroth / first / second moment of the tilted
+    distribution Phi(sign f) N(f | v/tau, 1/tau).  y in {1} -> +1, {0, -1} -> -1."""
+    sign = 1.0 if y == 1 else -1.0
+    z = sign * v_cav / np.sqrt(tau_cav ** 2 + tau_cav)
+    phi_div_Phi = deriv_log_cdf_normal(z)
+    log_Z_hat = log_cdf_normal(z)
+    mu_hat = v_cav / tau_cav + sign * phi_div_Phi / np.sqrt(tau_cav ** 2 + tau_cav)
+    sigma2_hat = 1.0 / tau_cav - (phi_div_Phi / (tau_cav ** 2 + tau_cav)) * (z + phi_div_Phi)
+    return np.exp(log_Z_hat), mu_hat, sigma2_hat
+
+
+def ep_recompute(K, tau, v):
+    """posteriorParams._recompute: Sigma, mu and chol(B), B = I + S^1/2 K S^1/2."""
+    n = tau.size
+    root = np.sqrt(tau)
+    SrK = root[:, None] * K
+    B = np.eye(n) + SrK * root[None, :]
+    L = jitchol(B)
+    V = dtrtrs(L, SrK, lower=1)
+    Sigma = K - np.dot(V.T, V)
+    aux = dpotrs(L, root * np.dot(K, v), lower=1)
+    alpha = v - root * aux
+    mu = np.dot(K, alpha)
+    return mu, Sigma, L
+
+
+def expectation_propagation(K, y, order_fn=None, epsilon=1e-6, eta=1.0, delta=1.0, max_iters=10 ** 6):
+    """EP.expectation_propagation.  ``order_fn(n)`` yields the site order of a sweep (upstream:
+    np.random.permutation(n)).  Returns the site parameters, cavity parameters, the tilted moments of the
+    last sweep, log_Z_tilde and the number of sweeps."""
+    n = y.size
+    if order_fn is None:
+        order_fn = np.random.permutation
+    tau, v = np.zeros(n), np.zeros(n)
+    tau_cav, v_cav = np.zeros(n), np.zeros(n)
+    Z_hat, mu_hat, s2_hat = np.zeros(n), np.zeros(n), np.zeros(n)
+    mu, Sigma = np.zeros(n), K.copy()
+    upd = np.empty_like(Sigma)
+    tau_old = v_old = None
+    it = 0
+    stop = False
+    while not stop and it < max_iters:
+        for i in order_fn(n):
+            tau_cav[i] = 1.0 / Sigma[i, i] - eta * tau[i]
+            v_cav[i] = mu[i] / Sigma[i, i] - eta * v[i]
+            Z_hat[i], mu_hat[i], s2_hat[i] = bernoulli_moments_match_ep(y[i], tau_cav[i], v_cav[i])
+            d_tau = delta / eta * (1.0 / s2_hat[i] - 1.0 / Sigma[i, i])
+            d_v = delta / eta * (mu_hat[i] / s2_hat[i] - mu[i] / Sigma[i, i])
+            prev = tau[i]
+            tau[i] += d_tau
+            if tau[i] < _EPS:
+                tau[i] = _EPS
+                d_tau = tau[i] - prev
+            v[i] += d_v
+            ci = d_tau / (1.0 + d_tau * Sigma[i, i])
+            s = Sigma[:, i].copy()
+            np.multiply(s[:, None], (ci * s)[None, :], out=upd)    # upstream: DSYR on the lower triangle + symmetrify
+            Sigma -= upd
+            mu = np.dot(Sigma, v)
+        mu, Sigma, _ = ep_recompute(K, tau, v)
+        if it > 0:
+            stop = (np.mean(np.square(tau - tau_old)) < epsilon) and (np.mean(np.square(v - v_old)) < epsilon)
+        tau_old, v_old = tau.copy(), v.copy()
+        it += 1
+    log_Z_tilde = np.sum(np.log(Z_hat) + 0.5 * LOG_2_PI + 0.5 * np.log(1.0 + tau / tau_cav)
+                         - 0.5 * (v ** 2) / (tau_cav + tau)
+                         + 0.5 * (v_cav * ((tau / tau_cav) * v_cav - 2.0 * v) / (tau_cav + tau)))
+    return dict(tau=tau, v=v, tau_cav=tau_cav, v_cav=v_cav, Z_hat=Z_hat, mu_hat=mu_hat, sigma2_hat=s2_hat,
+                log_Z_tilde=float(log_Z_tilde), sweeps=it)
+
+
+def ep_inference(kern, X, sites):
+    """EP._inference / _ep_marginal for FIXED site parameters (what every objective evaluation of one optimize()
+    call is in ep_mode "alt"): log marginal, woodbury vector / inverse, dL_dK."""
+    kern = as_add(kern)
+    K = kern.K(X)
+    tau, v = sites["tau"], sites["v"]
+    mu, Sigma, L = ep_recompute(K, tau, v)
+    n = tau.size
+    B_logdet = np.sum(2.0 * np.log(np.diag(L)))
+    log_marginal = 0.5 * (-n * LOG_2_PI - B_logdet + np.sum(v * np.dot(Sigma, v))) + sites["log_Z_tilde"]
+    root = np.sqrt(tau)
+    SrK = root[:, None] * K
+    aux = dpotrs(L, np.dot(SrK, v), lower=1)
+    alpha = (v - root * aux)[:, None]
+    LWi = dtrtrs(L, np.diag(root), lower=1)
+    Wi = np.dot(LWi.T, LWi)
+    dL_dK = 0.5 * (tdot(alpha) - Wi)
+    return dict(log_marginal=float(log_marginal), woodbury_vector=alpha, woodbury_inv=Wi, K=K, dL_dK=dL_dK,
+                mu=mu, Sigma_diag=np.diag(Sigma).copy())
+
+
+def bernoulli_predictive_mean(mu, var):
+    """Bernoulli.predictive_mean with the probit link: Phi(mu / sqrt(1 + var))  (GP.predict of a classifier,
+    gp_model/base.py:187 -> classification.py:83,99)."""
+    return _special.ndtr(mu / np.sqrt(1.0 + var))
+
+
+# --------------------------------------------------------------------------
 # Posterior._raw_predict + GP.predict + GP.predictive_gradients
 # (gp_model/base.py:187, :206, :222)
 # --------------------------------------------------------------------------

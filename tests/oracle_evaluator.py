@@ -42,6 +42,9 @@ class OracleEvaluator:
 
     def _post(self, model):
         k = self._kern(model)
+        if getattr(model, "is_classifier", False):
+            inf = go.ep_inference(k, model.X, self._ensure_sites(model))
+            return k, model.X, inf["woodbury_vector"], inf["woodbury_inv"]
         if model.is_sparse:
             inf = go.vardtc_inference(k, model.X, model.Z, model.noise_variance, model.Y_normalized)
             return k, model.Z, inf["woodbury_vector"], inf["woodbury_inv"]
@@ -60,3 +63,21 @@ class OracleEvaluator:
     def predict_train(self, model, want_mean=True, want_grad=True):
         mu = self.predict(model, model.X, False)[0] if want_mean else None
         return mu, (self.predict_grad(model, model.X) if want_grad else None)
+
+    # -- GP classification (EP) ----------------------------------------------------------
+    def _ensure_sites(self, model):
+        if model._sites is None:
+            k = self._kern(model)
+            sites = go.expectation_propagation(k.K(model.X), model.Y[:, 0], epsilon=model.ep_epsilon, eta=model.ep_eta,
+                                               delta=model.ep_delta)
+            model._set_sites(sites["tau"], sites["v"], sites["log_Z_tilde"], sites["sweeps"])
+        return dict(tau=model._sites[0], v=model._sites[1], log_Z_tilde=model._sites[2])
+
+    def ep_lml(self, model):
+        return go.ep_inference(self._kern(model), model.X, self._ensure_sites(model))["log_marginal"]
+
+    def ep_lml_grad(self, model):
+        k = self._kern(model)
+        inf = go.ep_inference(k, model.X, self._ensure_sites(model))
+        dvar, dlen = self._expand(k, k.param_gradients_full(inf["dL_dK"], model.X, None))
+        return inf["log_marginal"], dvar, dlen
