@@ -18,9 +18,14 @@ LIB = os.path.join(HERE, "libedrgp_hip.so")
 SOURCES = ["api.hip", "sparse_eval.hip", "sweep_eval.hip", "ep_eval.hip", "la_gemm.hip", "la_gemm32.hip", "la_chol.hip", "la_vec.hip", "gp_kernels.hip", "comm.hip", "calib.hip"]
 HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + \
           [os.path.join(HERE, "..", "include", "edrgp_hip.h")]
+# probe builds (never the product): EDRGP_BUILD_VARIANT=stamps -> libedrgp_hip_stamps.so with -DEDRGP_TILE_STAMPS
+VARIANT = os.environ.get("EDRGP_BUILD_VARIANT", "")
+if VARIANT:
+    OBJ = os.path.join(HERE, "csrc", "_obj_" + VARIANT)
+    LIB = os.path.join(HERE, "libedrgp_hip_%s.so" % VARIANT)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result",
-         "-I/opt/rocm/include"]
+         "-I/opt/rocm/include"] + ({"stamps": ["-DEDRGP_TILE_STAMPS"]}.get(VARIANT, []))
 
 
 def _stale(target, deps):

@@ -370,6 +370,11 @@ int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
     else if (!std::strcmp(key, "overlap")) c->overlap = (int)value;
     else if (!std::strcmp(key, "trace")) c->trace = (value != 0.0);
     else if (!std::strcmp(key, "gemm_dephase")) c->gemm_dephase = (int)value;
+    else if (!std::strcmp(key, "gemm_alias")) c->gemm_alias = (int)value;
+    else if (!std::strcmp(key, "gemm_persist")) c->gemm_persist = (int)value;
+    else if (!std::strcmp(key, "kmm_early")) c->kmm_early = (int)value;
+    else if (!std::strcmp(key, "side_gemm_pad")) c->side_gemm_pad = (int)value;
+    else if (!std::strcmp(key, "skinny_split")) c->skinny_split = (int)value;
     else if (!std::strcmp(key, "fuse_grad")) c->fuse_grad = (value != 0.0);
     else if (!std::strcmp(key, "tri_tile")) g_tri_tile = (int)value;
     else if (!std::strcmp(key, "mfma_kbuild")) c->mfma_kbuild = (value != 0.0);

@@ -244,6 +244,12 @@ struct Ctx {
     bool chol_inv_fused = true;       // ... and the inverse of the factor out of the same launches
     bool rbf_epilogue = true;         // RBF: fused gradient epilogue takes h(r) = -k(r) from the resident K_nm
     bool fuse_grad = true;            // fused Q .* h epilogue of the gradient contraction (single-part kernels, D <= 32)
+    int skinny_split = 1;             // split-K for skinny outputs with 64 <= k-tiles < 256 (la_gemm.hip)
+    int side_gemm_pad = 0;            // see gemm_pad_now
+    int gemm_pad_now = 0;             // dynamic LDS padding of the 64 x 64 products queued beside a factorisation (bytes)
+    int kmm_early = 1;                // Kmm-term products that need A only run beside the factorisation of B
+    int gemm_persist = 1;             // gradient contraction as a persistent grid (la_gemm.hip)
+    int gemm_alias = 0;               // timing probe of the contraction (wrong results): la_gemm.hip dbg_alias
     int gemm_dephase = 3;             // see la_gemm.hip: 3 = staging / barrier phases at raised priority
     bool trace = false;
     bool sync_free = true;            // sparse evaluations wait for the device once, at the end (sparse_eval.hip)

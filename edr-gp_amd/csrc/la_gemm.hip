@@ -20,6 +20,8 @@
 #include "common.h"
 #include "kfun.h"
 #include <cstdlib>
+#include <cstdio>
+#include <vector>
 
 namespace edrgp {
 
@@ -68,6 +70,8 @@ struct GemmArgs {
     int fuse_on;
     int dephase;        // 0 none; 1 s_setprio on odd wave slots; 2 half-tile start delay on odd wave slots
     int xmap;           // 1: split-major XCD map (see the kernel)
+    int persist;        // TAG 2: > 0 = tile count of a persistent launch (grid = 2 workgroups per CU)
+    int dbg_alias;      // TIMING PROBE ONLY (wrong results): bit0 A tiles alias 4 row tiles, bit1 B tiles alias column tile 0
     int diag_opt;       // 1: diagonal tiles of the Phi contraction compute their lower blocks only
     int kmode;          // triangular operands: bit0 k <= row tile end, bit1 k >= row tile start,
                         //                      bit2 k <= col tile end, bit3 k >= col tile start
@@ -399,10 +403,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) double As[2][LA::SIZE];
     __shared__ __attribute__((aligned(16))) double Bs[2][LB::SIZE];
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int lr = lane & 15, lq = lane >> 4;
+    const int tid0 = threadIdx.x;
+#ifdef EDRGP_TILE_STAMPS
+    // probe build (tools/tile_stamps.py): wall-clock stamps (100 MHz) of this workgroup's phases, contraction only
+    unsigned long long ts_entry = 0, ts_loop = 0, ts_loop_end = 0;
+    if (TAG == 2) ts_entry = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // Two workgroups share a CU (two waves per SIMD).  Launched together and doing
     // identical work they run in lockstep, so their barrier / staging phases coincide
@@ -467,13 +473,46 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     // Zero-skipping over a lower-triangular right operand gives column tile j a k-range of (j + 1) tiles: paired
     // (T-1-p, p), every workgroup runs T + 1 of them and half as many workgroups pay prologue and drain.
     const int tj_second = g.tiles_n - 1 - tj;
-    const int npass = (TAG == 4 && g.pair && tj_second != tj) ? 2 : 1;
+    int npass = (TAG == 4 && g.pair && tj_second != tj) ? 2 : 1;
+    // Persistent contraction (TAG 2, g.persist = number of tiles): the grid is two workgroups per CU and each walks a
+    // fixed list of tiles.  A fresh workgroup reaches a freed slot ~19 us after its predecessor left (measured,
+    // tools/tile_stamps.py: 49 turnovers per CU = 0.9 ms with half the matrix pipe's feed), a resident one starts its
+    // next tile at once.  Workgroups b, b + 8, ... share an XCD and take that XCD's contiguous eighth of the tiles 64
+    // at a time, so the workgroups running together still share their K_nm row panels in the L2.
+    int p_start = 0, p_len = 0, p_per = 1, p_in = 0;
+    if (TAG == 2 && g.persist) {
+        const int total = g.persist;
+        const int q = total >> 3, r = total & 7, x = (int)blockIdx.x & 7;
+        p_in = (int)blockIdx.x >> 3;
+        p_per = (int)gridDim.x >> 3;
+        p_start = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q);
+        p_len = q + (x < r ? 1 : 0);
+        npass = (p_len - p_in + p_per - 1) / p_per;
+    }
 #pragma clang loop unroll(disable)
     for (int pass = 0; pass < npass; ++pass) {
-    if (pass == 1) {
+    if (TAG == 2 && g.persist) {
+        t = p_start + pass * p_per + p_in;
+        ti = t / g.tiles_n;
+        tj = t - ti * g.tiles_n;
+        if (pass) __syncthreads();                     // the previous tile's epilogue is done with the LDS
+#ifdef EDRGP_TILE_STAMPS
+        ts_entry = __builtin_amdgcn_s_memrealtime();
+#endif
+    } else if (pass == 1) {
         tj = tj_second;
         __syncthreads();                               // the first tile's epilogue is done with the LDS
     }
+
+    // The thread index is re-derived per tile behind an opaque barrier (TAG 2): otherwise every per-thread address of
+    // the loaders and the epilogue is hoisted out of the tile loop of a persistent launch and kept alive across it
+    // (249 -> 256 VGPRs + 164 B of scratch per lane).
+    int tid_l = tid0;
+    if (TAG == 2 || TAG == 4) asm volatile("" : "+v"(tid_l));
+    const int tid = tid_l;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, lq = lane >> 4;
 
     const int z = blockIdx.z;
     int Meff = g.M, Keff = g.K;
@@ -538,8 +577,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                           ((long long)(AKM ? BK : BM) * g.lda < (1LL << 28)) &&
                           ((long long)(BKM ? BK : BN) * g.ldb < (1LL << 28));
         unsigned offA[TileLoader<BM, AKM>::NV], offB[TileLoader<BN, BKM>::NV];
-        const char* baseA = reinterpret_cast<const char*>(A + TileLoader<BM, AKM>::tile_origin(g.lda, m0, kt0));
-        const char* baseB = reinterpret_cast<const char*>(B + TileLoader<BN, BKM>::tile_origin(g.ldb, n0, kt0));
+        const int m0l = (g.dbg_alias & 1) ? m0 % (4 * BM) : m0, n0l = (g.dbg_alias & 2) ? 0 : n0;
+        const char* baseA = reinterpret_cast<const char*>(A + TileLoader<BM, AKM>::tile_origin(g.lda, m0l, kt0));
+        const char* baseB = reinterpret_cast<const char*>(B + TileLoader<BN, BKM>::tile_origin(g.ldb, n0l, kt0));
         const long long stepA = TileLoader<BM, AKM>::tile_step(g.lda), stepB = TileLoader<BN, BKM>::tile_step(g.ldb);
         if (fast) {
             la.offsets(offA, g.lda, tid);
@@ -553,6 +593,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         la.store(As[0], tid);
         lb.store(Bs[0], tid);
         __syncthreads();
+#ifdef EDRGP_TILE_STAMPS
+        if (TAG == 2) ts_loop = __builtin_amdgcn_s_memrealtime();
+#endif
         // TAG 9 = diagnostic build of the Phi kernel: per-wave cycle sums of the loop
         // phases (load issue / MFMA / wait+LDS store / barrier), never used in production
         unsigned long long st_load = 0, st_mfma = 0, st_store = 0, st_bar = 0, st_t = 0;
@@ -624,6 +667,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
             GEMM_STAMP(st_bar)
         }
 #undef GEMM_STAMP
+#ifdef EDRGP_TILE_STAMPS
+        if (TAG == 2) ts_loop_end = __builtin_amdgcn_s_memrealtime();
+#endif
         if (TAG == 9 && g.stamps != nullptr && lane == 0 && blockIdx.x == 5 && blockIdx.y == 2) {
             unsigned long long* o = g.stamps + wave * 4;
             o[0] = st_load; o[1] = st_mfma; o[2] = st_store; o[3] = st_bar;
@@ -758,7 +804,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                     }
                 }
             fused_epilogue_reduce<BN, WN, TN>(f, csum, dv, &Bs[0][0], tid, wm, wn, lr, lq, n0, g.N, ti,
-                                              (size_t)blockIdx.z * gridDim.x + blockIdx.x);
+                                              g.persist ? (size_t)t : (size_t)blockIdx.z * gridDim.x + blockIdx.x);
+#ifdef EDRGP_TILE_STAMPS
+            if (TAG == 2 && g.stamps != nullptr && tid == 0) {
+                unsigned long long* o = g.stamps + (size_t)(g.persist ? t : (int)blockIdx.x) * 6;
+                o[0] = ts_entry; o[1] = ts_loop; o[2] = ts_loop_end; o[3] = __builtin_amdgcn_s_memrealtime();
+                o[4] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);      // HW_ID
+                o[5] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);     // XCC_ID
+            }
+#endif
             continue;
         }
         // one feature chunk (the host fuses only when D <= DC): stage, then one row block
@@ -828,7 +882,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
             }
         }
         fused_epilogue_reduce<BN, WN, TN>(f, csum, dv, &Bs[0][0], tid, wm, wn, lr, lq, n0, g.N, ti,
-                                          (size_t)blockIdx.z * gridDim.x + blockIdx.x);
+                                          g.persist ? (size_t)t : (size_t)blockIdx.z * gridDim.x + blockIdx.x);
         continue;
     }
 
@@ -914,15 +968,15 @@ __global__ void slab_reduce_kernel(const double* __restrict__ slabs, int splits,
 
 template <int BM, int BN>
 static void launch_variant(bool akm, bool bkm, int tag, dim3 grid, hipStream_t s, const GemmArgs& g, unsigned dyn_lds) {
-    if (tag == 9 && akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, true, 9>), grid, dim3(256), 0, s, g);
-    else if (tag == 1 && akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, true, 1>), grid, dim3(256), 0, s, g);
-    else if (tag == 2 && !akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, true, 2>), grid, dim3(256), 0, s, g);
+    if (tag == 9 && akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, true, 9>), grid, dim3(256), dyn_lds, s, g);
+    else if (tag == 1 && akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, true, 1>), grid, dim3(256), dyn_lds, s, g);
+    else if (tag == 2 && !akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, true, 2>), grid, dim3(256), dyn_lds, s, g);
     else if (tag == 3 && !akm && !bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, false, 3>), grid, dim3(256), dyn_lds, s, g);
-    else if (tag == 4 && !akm && !bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, false, 4>), grid, dim3(256), 0, s, g);
-    else if (akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, true, 0>), grid, dim3(256), 0, s, g);
-    else if (akm && !bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, false, 0>), grid, dim3(256), 0, s, g);
-    else if (!akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, true, 0>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, false, 0>), grid, dim3(256), 0, s, g);
+    else if (tag == 4 && !akm && !bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, false, 4>), grid, dim3(256), dyn_lds, s, g);
+    else if (akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, true, 0>), grid, dim3(256), dyn_lds, s, g);
+    else if (akm && !bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, false, 0>), grid, dim3(256), dyn_lds, s, g);
+    else if (!akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, true, 0>), grid, dim3(256), dyn_lds, s, g);
+    else hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, false, 0>), grid, dim3(256), dyn_lds, s, g);
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -952,6 +1006,7 @@ static int gemm_impl(Ctx* c, bool transA, bool transB, int M, int N, int K, doub
     g.xmap = (o.tag == 1 || o.tag == 9) && o.tri && splits > 1 && o.batch == 1 && c->syrk_xmap;
     g.diag_opt = 0;
     g.dephase = c->gemm_dephase;
+    g.dbg_alias = (o.tag == 2) ? c->gemm_alias : 0;
     g.stamps = nullptr;
     g.fuse_on = 0;
     if (o.tag == 3 || o.tag == 4) {
@@ -994,14 +1049,38 @@ static int gemm_impl(Ctx* c, bool transA, bool transB, int M, int N, int K, doub
     g.pair = (o.tag == 4 && (o.kmode == K_LE_COL) && g.tiles_n >= 2 && c->gemm_pair) ? 1 : 0;
     if (g.pair) nt = (long long)g.tiles_m * ((g.tiles_n + 1) / 2);
     if (g.diag_opt) nt = (long long)g.tiles_m * (g.tiles_m - 1) / 2 + (g.tiles_m + 1) / 2;
-    dim3 grid((unsigned)nt, (unsigned)splits, (unsigned)o.batch);
+    // the gradient contraction with its fused epilogue runs as a persistent grid when it has more than three rounds of tiles
+    g.persist = 0;
+    long long gx = nt;
+    if (o.tag == 2 && g.fuse_on && tile == 128 && c->gemm_persist && nt > 6LL * c->num_cu && nt < (1LL << 30)) {
+        g.persist = (int)nt;
+        gx = 2LL * c->num_cu;                          // a multiple of 8 (XCDs)
+        if (gx % 8) { g.persist = 0; gx = nt; }
+    }
+    dim3 grid((unsigned)gx, (unsigned)splits, (unsigned)o.batch);
     // op(A) is M x K: not transposed -> stored [M][K] (m-major); transposed -> stored [K][M] (k-major)
     const bool akm = transA;
     // op(B) is K x N: not transposed -> stored [K][N] (k-major); transposed -> stored [N][K]
     const bool bkm = !transB;
+#ifdef EDRGP_TILE_STAMPS
+    static unsigned long long* stamp_dev = nullptr;
+    const size_t stamp_bytes = (size_t)nt * 6 * sizeof(unsigned long long);
+    if (o.tag == 2 && g.fuse_on && getenv("EDRGP_TILE_STAMPS_FILE") != nullptr) {
+        if (stamp_dev == nullptr) HIP_TRY(hipMalloc(&stamp_dev, 64u << 20));
+        if (stamp_bytes <= (64u << 20)) { HIP_TRY(hipMemsetAsync(stamp_dev, 0, stamp_bytes, c->stream)); g.stamps = stamp_dev; }
+    }
+#endif
     if (tile == 128) launch_variant<128, 128>(akm, bkm, o.tag, grid, c->stream, g, (unsigned)o.dyn_lds);
-    else launch_variant<64, 64>(akm, bkm, o.tag, grid, c->stream, g, (unsigned)o.dyn_lds);
+    else launch_variant<64, 64>(akm, bkm, o.tag, grid, c->stream, g, (unsigned)(o.dyn_lds ? o.dyn_lds : c->gemm_pad_now));
     HIP_TRY(hipGetLastError());
+#ifdef EDRGP_TILE_STAMPS
+    if (o.tag == 2 && g.stamps == stamp_dev && stamp_dev != nullptr) {       // every launch overwrites the file: the last one stays
+        std::vector<unsigned long long> hst((size_t)nt * 6);
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(hst.data(), stamp_dev, stamp_bytes, hipMemcpyDeviceToHost));
+        if (FILE* fp = fopen(getenv("EDRGP_TILE_STAMPS_FILE"), "wb")) { fwrite(hst.data(), 1, stamp_bytes, fp); fclose(fp); }
+    }
+#endif
     return EDRGP_OK;
 }
 
@@ -1015,6 +1094,11 @@ int gemm(Ctx* c, bool transA, bool transB, int M, int N, int K, double alpha, co
         const int kt = (K + BK - 1) / BK;
         if (nt < 256 && kt >= 256) {
             splits = (int)std::min<long long>((1024 + nt - 1) / nt, kt / 32);
+            if (splits < 1) splits = 1;
+        } else if (nt <= 128 && kt >= 64 && o.kmode == 0 && o.tag == 0 && c->skinny_split) {
+            // skinny outputs with a medium k (the Kmm term's M x (2D+1) products at M = 2048: 64 workgroups of 128
+            // k-tiles on 256 CUs, 190 us each): two rounds of shorter workgroups
+            splits = (int)std::min<long long>((512 + nt - 1) / nt, kt / 16);
             if (splits < 1) splits = 1;
         }
     }

@@ -112,6 +112,7 @@ struct SparseEval {
     bool prebuilt = false;        // K_nm (and b) of the single row chunk were built beside phase 1
     bool kmmi_done = false;       // Kmm^-1 = Li^T Li was formed on the side stream
     bool kmmi_pending = false;    // ... and the main stream has not waited for it yet
+    bool tma_done = false;        // Lm^-T A Lm^-1 (Kmm term) was formed on the side stream beside the factorisation of B
     bool k32_resident = false;
     // precision 32 asks for the fp32 row pass; it is used while the Gram form is safe in fp32 (error ~ eps32
     // cond(Kmm), judged by the pivot-ratio proxy after phase 1), otherwise this evaluation falls back to the fp64
@@ -177,7 +178,7 @@ struct SparseEval {
         f32 = want32 && c->f32_phi && !c->phi32_bad;
         // the fused one-launch-per-step factorisation covers n in (64, 3072]; outside it the explicit inverse stays
         rhs_row = !need_grad && !need_post && c->chol_rhs && c->chol_fused && M > 64 && M + 1 <= 3072;
-        k_resident = prebuilt = kmmi_done = kmmi_pending = k32_resident = false;
+        k_resident = prebuilt = kmmi_done = kmmi_pending = tma_done = k32_resident = false;
         return EDRGP_OK;
     }
 
@@ -238,6 +239,7 @@ struct SparseEval {
     //  stable form: A = beta (K Li^T)^T (K Li^T), error ~ eps sqrt(cond).)
     // Exactly one all-reduce of [Phi | b] per call, whatever the local chunking.
     int phase2(bool stable_form) {
+        tma_done = false;                          // A follows Phi
         if (f32) {
             // fp32 row pass: K_nm stored and multiplied in fp32, Phi / b accumulated into fp64
             TRY(c->Knm32.reserve((size_t)chunk * M * sizeof(float)));
@@ -323,6 +325,7 @@ struct SparseEval {
             TRY(gemv_n(c, M, M, 1.0, Li, M, bvec, v_v));
         }
         TRY(trace_of(c, A, M, M, sc + SC_TRA));
+        TRY(kmm_products_beside_chol());
         const double bjit = 1.0 + (lvl >= 0 ? jit_amount(lvl, 1.0 + h_sc[SC_TRA] / Mr) : 0.0);
         if (rhs_row) {
             // bound only: the bound needs |c|^2, c = beta LB^-1 v, and log det LB, not LB^-1.  beta v rides
@@ -402,10 +405,37 @@ struct SparseEval {
         TRY(side.start_after_main());              // after the row pass: the Phi kernel keeps the GPU to itself
         {
             ProfScope ps(c, EDRGP_PROF_SMALL);
-            TRY(gram_of_lower(c, M, Li, c->mats[MAT_KMMI].d()));
+            c->gemm_pad_now = c->side_gemm_pad;
+            const int st = gram_of_lower(c, M, Li, c->mats[MAT_KMMI].d());
+            c->gemm_pad_now = 0;
+            if (st != EDRGP_OK) return st;
         }
         TRY(side.mark_done());
         kmmi_done = kmmi_pending = true;
+        return EDRGP_OK;
+    }
+
+    // The two M^3 products of the Kmm term that need A but not LB (C1 = Li^T A, Lm^-T A Lm^-1 = C1 Li) join Kmm^-1 on
+    // the side stream beside the factorisation of B.  They used to run beside the gradient contraction, which as a
+    // persistent grid leaves no slot to a second kernel: the whole Kmm chain then ran after it (1.2 ms at Cm).
+    int kmm_products_beside_chol() {
+        if (!need_grad || !c->overlap || !c->kmm_early || tma_done) return EDRGP_OK;
+        SideStream side(c);
+        TRY(side.start_after_main());
+        {
+            ProfScope ps(c, EDRGP_PROF_SMALL);
+            double* C1 = c->mats[MAT_C1].d();
+            // padded like the K_nm build beside phase 1: the LDS hole a finished workgroup leaves must take a
+            // factorisation step's workgroup
+            c->gemm_pad_now = c->side_gemm_pad;
+            int st = gemm(c, true, false, M, M, M, 1.0, Li, M, A, M, 0.0, C1, M, kopt(K_GE_ROW));
+            if (st == EDRGP_OK) st = gemm(c, false, false, M, M, M, 1.0, C1, M, Li, M, 0.0, c->mats[MAT_TMM].d(), M, kopt(K_GE_COL));
+            c->gemm_pad_now = 0;
+            if (st != EDRGP_OK) return st;
+        }
+        TRY(side.mark_done());                     // stream order: also covers Kmm^-1 queued before
+        tma_done = true;
+        kmmi_pending = true;                       // factors_queue waits for the side stream
         return EDRGP_OK;
     }
 
@@ -450,11 +480,16 @@ struct SparseEval {
         double* C1 = c->mats[MAT_C1].d();
         double* dKmm = c->mats[MAT_DKMM].d();
         double* Tmm = c->mats[MAT_TMM].d();
-        // C1 = Li^T A ; Tm = C1 Li = Lm^-T A Lm^-1
-        TRY(gemm(c, true, false, M, M, M, 1.0, Li, M, A, M, 0.0, C1, M, kopt(K_GE_ROW)));
-        TRY(gemm(c, false, false, M, M, M, 1.0, C1, M, Li, M, 0.0, Tm, M, kopt(K_GE_COL)));
+        // C1 = Li^T A ; Tm = C1 Li = Lm^-T A Lm^-1 (already in Tmm when formed beside the factorisation of B)
+        const double* LtAL = Tm;
+        if (tma_done) {
+            LtAL = Tmm;
+        } else {
+            TRY(gemm(c, true, false, M, M, M, 1.0, Li, M, A, M, 0.0, C1, M, kopt(K_GE_ROW)));
+            TRY(gemm(c, false, false, M, M, M, 1.0, C1, M, Li, M, 0.0, Tm, M, kopt(K_GE_COL)));
+        }
         // dL/dKmm = 1/2 Kmm^-1 - 1/2 P - 1/2 wv wv^T - 1/2 Lm^-T A Lm^-1
-        TRY(combine3(c, M, 0.5, Kmmi, -0.5, P, -0.5, Tm, -0.5, v_wv, dKmm));
+        TRY(combine3(c, M, 0.5, Kmmi, -0.5, P, -0.5, LtAL, -0.5, v_wv, dKmm));
         for (int p = 0; p < np; ++p) {
             TRY(grad_elementwise(c, ks, p, c->Z.d(), nullptr, M, c->Z.d(), M, dKmm, M, 0.0, nullptr, Tmm, M,
                                  sc + SC_DVAR_MM + p));
