@@ -375,6 +375,12 @@ int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
     else if (!std::strcmp(key, "kmm_early")) c->kmm_early = (int)value;
     else if (!std::strcmp(key, "side_gemm_pad")) c->side_gemm_pad = (int)value;
     else if (!std::strcmp(key, "skinny_split")) c->skinny_split = (int)value;
+    else if (!std::strcmp(key, "gemm_interleave")) c->gemm_interleave = (int)value;
+    else if (!std::strcmp(key, "mid_split")) c->mid_split = (int)value;
+    else if (!std::strcmp(key, "dbg_gemm_kmode")) c->dbg_gemm_kmode = (int)value;
+    else if (!std::strcmp(key, "dbg_gemm_tri")) c->dbg_gemm_tri = (int)value;
+    else if (!std::strcmp(key, "dbg_gemm_tile")) c->dbg_gemm_tile = (int)value;
+    else if (!std::strcmp(key, "dbg_gemm_reps")) c->dbg_gemm_reps = (int)value;
     else if (!std::strcmp(key, "fuse_grad")) c->fuse_grad = (value != 0.0);
     else if (!std::strcmp(key, "tri_tile")) g_tri_tile = (int)value;
     else if (!std::strcmp(key, "mfma_kbuild")) c->mfma_kbuild = (value != 0.0);
@@ -782,7 +788,13 @@ int edrgp_dbg_gemm(edrgp_ctx* ctx, int transA, int transB, int M, int N, int K, 
     HIP_TRY(hipMemcpy(dA.d(), A, ra * lda * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dB.d(), B, rb * ldb * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dC.d(), C, (size_t)M * ldc * sizeof(double), hipMemcpyHostToDevice));
-    int s = gemm(c, transA != 0, transB != 0, M, N, K, alpha, dA.d(), lda, dB.d(), ldb, beta, dC.d(), ldc);
+    // options dbg_gemm_kmode / dbg_gemm_tri / dbg_gemm_tile: the zero-skipping / lower-tiles-only / tile-size variants
+    // the evaluation uses for its M x M x M products (tools/mid_gemm_probe.py)
+    GemmOpts go = kopt(c->dbg_gemm_kmode, c->dbg_gemm_tri);
+    if (c->dbg_gemm_tile > 0) go.force_tile = c->dbg_gemm_tile;
+    int s = gemm(c, transA != 0, transB != 0, M, N, K, alpha, dA.d(), lda, dB.d(), ldb, beta, dC.d(), ldc, go);
+    for (int rep = 1; rep < c->dbg_gemm_reps && s == EDRGP_OK; ++rep)
+        s = gemm(c, transA != 0, transB != 0, M, N, K, alpha, dA.d(), lda, dB.d(), ldb, beta, dC.d(), ldc, go);
     if (s == EDRGP_OK && hipStreamSynchronize(c->stream) != hipSuccess) { set_error("dbg_gemm: kernel failed"); s = EDRGP_ERR_HIP; }
     if (s == EDRGP_OK) HIP_TRY(hipMemcpy(C, dC.d(), (size_t)M * ldc * sizeof(double), hipMemcpyDeviceToHost));
     dA.release(); dB.release(); dC.release();

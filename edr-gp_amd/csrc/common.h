@@ -110,6 +110,7 @@ struct GemmOpts {
     int limM_base = 0, limM_stride = 0;      // M_eff(z) = min(M, limM_base - z*limM_stride)
     int limK_base = 0, limK_stride = 0;      // K_eff(z) likewise
     int tri = 0;                             // 1: only tiles with ti >= tj (M == N)
+    int mirror_out = 0;                      // with tri: the upper triangle is filled from the lower one (symmetric result)
     int kmode = 0;                           // zero-skipping for triangular operands, see K_* below
     int force_tile = 0;                      // 64 or 128; 0 = heuristic; -1 = 128 if that gives >= 1024 tiles, else small_tile
     int small_tile = 64;
@@ -244,6 +245,9 @@ struct Ctx {
     bool chol_inv_fused = true;       // ... and the inverse of the factor out of the same launches
     bool rbf_epilogue = true;         // RBF: fused gradient epilogue takes h(r) = -k(r) from the resident K_nm
     bool fuse_grad = true;            // fused Q .* h epilogue of the gradient contraction (single-part kernels, D <= 32)
+    int dbg_gemm_kmode = 0, dbg_gemm_tri = 0, dbg_gemm_tile = 0, dbg_gemm_reps = 1;   // edrgp_dbg_gemm only
+    int mid_split = 4;                // k-segments of lower-tiles-only products over triangular operands (la_gemm.hip)
+    int gemm_interleave = 2;          // zero-skipping products: 1 tiles dealt round-robin to the XCDs, 2 also length-ranked snake over the CUs (la_gemm.hip)
     int skinny_split = 1;             // split-K for skinny outputs with 64 <= k-tiles < 256 (la_gemm.hip)
     int side_gemm_pad = 0;            // see gemm_pad_now
     int gemm_pad_now = 0;             // dynamic LDS padding of the 64 x 64 products queued beside a factorisation (bytes)

@@ -86,8 +86,9 @@ inline GemmOpts kopt(int kmode, int tri = 0, int tag = 0) {
 
 // C (n x n, symmetric) = L^T L for lower-triangular L: lower tiles, zero-skipping, mirrored
 inline int gram_of_lower(Ctx* c, int n, const double* L, double* C) {
-    TRY(gemm(c, true, false, n, n, n, 1.0, L, n, L, n, 0.0, C, n, kopt(K_GE_ROW | K_GE_COL, 1)));
-    return mirror_lower(c, C, n, n);
+    GemmOpts o = kopt(K_GE_ROW | K_GE_COL, 1);
+    o.mirror_out = 1;
+    return gemm(c, true, false, n, n, n, 1.0, L, n, L, n, 0.0, C, n, o);
 }
 
 inline KSpec make_kspec(const Ctx* c) {

@@ -70,6 +70,7 @@ struct GemmArgs {
     int fuse_on;
     int dephase;        // 0 none; 1 s_setprio on odd wave slots; 2 half-tile start delay on odd wave slots
     int xmap;           // 1: split-major XCD map (see the kernel)
+    int interleave;     // 1: tile = workgroup index (no XCD-contiguous remap): zero-skipping products
     int persist;        // TAG 2: > 0 = tile count of a persistent launch (grid = 2 workgroups per CU)
     int dbg_alias;      // TIMING PROBE ONLY (wrong results): bit0 A tiles alias 4 row tiles, bit1 B tiles alias column tile 0
     int diag_opt;       // 1: diagonal tiles of the Phi contraction compute their lower blocks only
@@ -437,6 +438,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         const int w = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + in;
         split = w / nt;
         t = w - split * nt;
+    } else if (g.interleave >= 2) {
+        // one triangular operand, full output: tiles ranked by k-range (longest first) and dealt to the CUs in a
+        // snake -- pass 0 over the CUs ascending, pass 1 descending, ... -- so the workgroups sharing a CU have the same
+        // total.  Assumes the dispatcher's order (workgroup b -> XCD b % 8, CU (b / 8) % 32 of it, slot b / 256); any
+        // other order only loses the balance, the map stays a bijection.
+        const int b = blockIdx.x, x = b & 7, l = b >> 3, cu = l & 31, slot = l >> 5;
+        const int G = cu * 8 + x;
+        t = slot * 256 + ((slot & 1) ? 255 - G : G);
+    } else if (g.interleave) {
+        // zero-skipping products: a tile's k-range grows (or shrinks) with its index, so a contiguous eighth per XCD
+        // hands one XCD twice the mean work and another almost none; dealt round-robin every XCD (and, 32 tiles apart,
+        // every CU) gets the same mix
+        t = blockIdx.x;
     } else {
         const int bid = blockIdx.x;
         const int q = nt >> 3, r = nt & 7, x = bid & 7, in = bid >> 3;
@@ -466,6 +480,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         const int half = (g.tiles_n + 1) / 2;
         ti = t / half;
         tj = g.tiles_n - 1 - (t - ti * half);          // the long column tile first, its short partner second
+    } else if (g.interleave >= 2) {
+        const int km = g.interleave >> 1;              // the single k-range restriction this product has
+        if (km == 1)      { ti = g.tiles_m - 1 - t / g.tiles_n; tj = t % g.tiles_n; }      // k <= row end: last rows longest
+        else if (km == 2) { ti = t / g.tiles_n; tj = t % g.tiles_n; }                        // k >= row start: first rows
+        else if (km == 4) { tj = g.tiles_n - 1 - t / g.tiles_m; ti = t % g.tiles_m; }      // k <= col end: last columns
+        else              { tj = t / g.tiles_m; ti = t % g.tiles_m; }                        // k >= col start: first columns
     } else {
         ti = t / g.tiles_n;
         tj = t - ti * g.tiles_n;
@@ -955,7 +975,7 @@ __global__ void slab_reduce_kernel(const double* __restrict__ slabs, int splits,
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y * blockDim.y + threadIdx.y;
     if (i >= M || j >= N) return;
-    if (mirror && j > i) return;
+    if (mirror && j > i) return;                   // 1: both triangles written; 2: lower triangle only
     double s = 0.0;
     const double* p = slabs + (size_t)i * lds + j;
     for (int k = 0; k < splits; ++k) s += p[(size_t)k * slabStride];
@@ -963,7 +983,7 @@ __global__ void slab_reduce_kernel(const double* __restrict__ slabs, int splits,
     double* c = C + (size_t)i * ldc + j;
     if (beta != 0.0) v += beta * (*c);
     *c = v;
-    if (mirror && i != j) C[(size_t)j * ldc + i] = v;
+    if (mirror == 1 && i != j) C[(size_t)j * ldc + i] = v;
 }
 
 template <int BM, int BN>
@@ -992,7 +1012,9 @@ static int gemm_impl(Ctx* c, bool transA, bool transB, int M, int N, int K, doub
     }
     if (tile == 0) {
         const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * o.batch * splits;
-        tile = (M >= 128 && N >= 128 && t128 >= 96) ? 128 : 64;
+        // one 128 x 128 workgroup per CU runs at 47 TFLOP/s, four 64 x 64 ones at 54 (2048^3: 369 against 318 us): the
+        // large tile needs two workgroups per CU to pay
+        tile = (M >= 128 && N >= 128 && t128 >= 2LL * c->num_cu) ? 128 : 64;
     }
     GemmArgs g;
     g.A = A; g.B = B;
@@ -1006,6 +1028,7 @@ static int gemm_impl(Ctx* c, bool transA, bool transB, int M, int N, int K, doub
     g.xmap = (o.tag == 1 || o.tag == 9) && o.tri && splits > 1 && o.batch == 1 && c->syrk_xmap;
     g.diag_opt = 0;
     g.dephase = c->gemm_dephase;
+    g.interleave = (o.kmode != 0 && c->gemm_interleave) ? 1 : 0;
     g.dbg_alias = (o.tag == 2) ? c->gemm_alias : 0;
     g.stamps = nullptr;
     g.fuse_on = 0;
@@ -1046,6 +1069,9 @@ static int gemm_impl(Ctx* c, bool transA, bool transB, int M, int N, int K, doub
                  (M % 128 == 0) && (K % BK == 0) && g.vecA && ((long long)BK * lda < (1LL << 28)) && A == B && lda == ldb &&
                  o.batch == 1;
     long long nt = o.tri ? (long long)g.tiles_m * (g.tiles_m + 1) / 2 : (long long)g.tiles_m * g.tiles_n;
+    if (g.interleave && !o.tri && o.tag == 0 && splits == 1 && o.batch == 1 && c->gemm_interleave >= 2 && nt % 256 == 0 &&
+        (o.kmode == K_LE_ROW || o.kmode == K_GE_ROW || o.kmode == K_LE_COL || o.kmode == K_GE_COL) && c->num_cu == 256)
+        g.interleave = 2 * o.kmode;
     g.pair = (o.tag == 4 && (o.kmode == K_LE_COL) && g.tiles_n >= 2 && c->gemm_pair) ? 1 : 0;
     if (g.pair) nt = (long long)g.tiles_m * ((g.tiles_n + 1) / 2);
     if (g.diag_opt) nt = (long long)g.tiles_m * (g.tiles_m - 1) / 2 + (g.tiles_m + 1) / 2;
@@ -1102,6 +1128,17 @@ int gemm(Ctx* c, bool transA, bool transB, int M, int N, int K, double alpha, co
             if (splits < 1) splits = 1;
         }
     }
+    // Lower-tiles-only products over triangular operands (A = Tm Li^T, R = LBi Li, P = R^T R, Kmm^-1 = Li^T Li at
+    // M = 2048): a sixth of the full flops, but 528 workgroups whose longest walks all of K -- 160-185 us, the time of
+    // its serial k-loop.  Cut along k into mid_split segments (empty ones leave at once) the chain is a quarter as
+    // long; the segments meet in the slab reduction, which also mirrors (tools/mid_gemm_probe.py).
+    int reduce_mode = 0;
+    if (o.batch == 1 && o.tri && o.kmode != 0 && o.tag == 0 && c->mid_split > 1 && M == N && K >= 1024 && M >= 1024 &&
+        true) {
+        splits = std::min(c->mid_split, (K + BK - 1) / BK / 16);
+        if (splits < 2) splits = 1;
+        reduce_mode = 2;
+    }
     if (splits > 1) {
         const long long slabStride = (long long)M * N;
         TRY(c->slabs.reserve((size_t)splits * slabStride * sizeof(double)));
@@ -1111,11 +1148,13 @@ int gemm(Ctx* c, bool transA, bool transB, int M, int N, int K, double alpha, co
                       c->slabs.d(), slabStride, N));
         dim3 blk(64, 4), grd((N + 63) / 64, (M + 3) / 4);
         hipLaunchKernelGGL(slab_reduce_kernel, grd, blk, 0, c->stream, c->slabs.d(), splits, slabStride, M, N,
-                           N, alpha, beta, C, ldc, 0);
+                           N, alpha, beta, C, ldc, reduce_mode ? (o.mirror_out ? 1 : 2) : 0);
         HIP_TRY(hipGetLastError());
         return EDRGP_OK;
     }
-    return gemm_impl(c, transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, o, 1, nullptr, 0, 0);
+    TRY(gemm_impl(c, transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, o, 1, nullptr, 0, 0));
+    if (o.tri && o.mirror_out) TRY(mirror_lower(c, C, M, ldc));
+    return EDRGP_OK;
 }
 
 __global__ void mirror_lower_kernel(double* __restrict__ A, int n, int lda) {

@@ -320,8 +320,9 @@ struct SparseEval {
         } else {
             TRY(gemm(c, false, false, M, M, M, 1.0, Li, M, Phi, M, 0.0, Tm, M, kopt(K_LE_ROW)));
             // A = beta (Li Phi) Li^T is symmetric: lower tiles only, then mirrored
-            TRY(gemm(c, false, true, M, M, M, beta, Tm, M, Li, M, 0.0, A, M, kopt(K_LE_COL, 1)));
-            TRY(mirror_lower(c, A, M, M));
+            GemmOpts oa = kopt(K_LE_COL, 1);
+            oa.mirror_out = 1;
+            TRY(gemm(c, false, true, M, M, M, beta, Tm, M, Li, M, 0.0, A, M, oa));
             TRY(gemv_n(c, M, M, 1.0, Li, M, bvec, v_v));
         }
         TRY(trace_of(c, A, M, M, sc + SC_TRA));
