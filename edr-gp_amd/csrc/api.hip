@@ -372,6 +372,7 @@ int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
     else if (!std::strcmp(key, "gemm_dephase")) c->gemm_dephase = (int)value;
     else if (!std::strcmp(key, "gemm_alias")) c->gemm_alias = (int)value;
     else if (!std::strcmp(key, "gemm_persist")) c->gemm_persist = (int)value;
+    else if (!std::strcmp(key, "syrk_persist")) c->syrk_persist = (int)value;
     else if (!std::strcmp(key, "kmm_early")) c->kmm_early = (int)value;
     else if (!std::strcmp(key, "side_gemm_pad")) c->side_gemm_pad = (int)value;
     else if (!std::strcmp(key, "skinny_split")) c->skinny_split = (int)value;

@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 #ifdef EDRGP_TILE_STAMPS
     // probe build (tools/tile_stamps.py): wall-clock stamps (100 MHz) of this workgroup's phases, contraction only
     unsigned long long ts_entry = 0, ts_loop = 0, ts_loop_end = 0;
-    if (TAG == 2) ts_entry = __builtin_amdgcn_s_memrealtime();
+    if (TAG == 2 || TAG == 1) ts_entry = __builtin_amdgcn_s_memrealtime();
 #endif
 
     // Two workgroups share a CU (two waves per SIMD).  Launched together and doing
@@ -499,8 +499,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     // tools/tile_stamps.py: 49 turnovers per CU = 0.9 ms with half the matrix pipe's feed), a resident one starts its
     // next tile at once.  Workgroups b, b + 8, ... share an XCD and take that XCD's contiguous eighth of the tiles 64
     // at a time, so the workgroups running together still share their K_nm row panels in the L2.
+    // Persistent Phi (TAG 1, g.persist = tiles x splits): the same for the Gram launch -- its 1536 workgroups of 2.2 ms
+    // in three rounds drifted apart by their turnovers and their unequal lengths (a diagonal-pair workgroup issues 18
+    // MFMAs per k-step against 16): mean residency 484 of 512 (tools/phi_stamps.py).  Units in (split, tile) order, an
+    // XCD's contiguous eighth 64 at a time: at most one diagonal-pair unit per workgroup.
     int p_start = 0, p_len = 0, p_per = 1, p_in = 0;
-    if (TAG == 2 && g.persist) {
+    if ((TAG == 2 || TAG == 1) && g.persist) {
         const int total = g.persist;
         const int q = total >> 3, r = total & 7, x = (int)blockIdx.x & 7;
         p_in = (int)blockIdx.x >> 3;
@@ -511,7 +515,24 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     }
 #pragma clang loop unroll(disable)
     for (int pass = 0; pass < npass; ++pass) {
-    if (TAG == 2 && g.persist) {
+    if (TAG == 1 && g.persist) {
+        const int w = p_start + pass * p_per + p_in;
+        const int per_split = g.persist / g.splits;
+        split = w / per_split;
+        t = w - split * per_split;
+        const int n_strict = g.tiles_m * (g.tiles_m - 1) / 2;          // persistent Phi launches have diag_opt
+        pair_d0 = -1;
+        if (t < n_strict) {
+            ti = (int)((sqrt(8.0 * (double)t + 1.0) + 1.0) * 0.5);
+            while ((long long)ti * (ti + 1) / 2 <= t) ++ti;
+            while ((long long)ti * (ti - 1) / 2 > t) --ti;
+            tj = t - (int)((long long)ti * (ti - 1) / 2);
+        } else {
+            pair_d0 = 2 * (t - n_strict);
+            ti = tj = pair_d0;
+        }
+        if (pass) __syncthreads();                     // the previous unit is done with the LDS
+    } else if (TAG == 2 && g.persist) {
         t = p_start + pass * p_per + p_in;
         ti = t / g.tiles_n;
         tj = t - ti * g.tiles_n;
@@ -528,7 +549,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     // the loaders and the epilogue is hoisted out of the tile loop of a persistent launch and kept alive across it
     // (249 -> 256 VGPRs + 164 B of scratch per lane).
     int tid_l = tid0;
-    if (TAG == 2 || TAG == 4) asm volatile("" : "+v"(tid_l));
+    if (TAG == 1 || TAG == 2 || TAG == 4) asm volatile("" : "+v"(tid_l));
     const int tid = tid_l;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -965,6 +986,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         }
     }
     }   // pass
+#ifdef EDRGP_TILE_STAMPS
+    if (TAG == 1 && g.stamps != nullptr && threadIdx.x == 0) {      // Phi: entry / exit of every workgroup, pair flag
+        unsigned long long* o = g.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 6;
+        o[0] = ts_entry; o[1] = (unsigned long long)(pair_d0 >= 0); o[2] = 0; o[3] = __builtin_amdgcn_s_memrealtime();
+        o[4] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+        o[5] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
+    }
+#endif
 }
 
 // C[i][j] = alpha * sum_s slab[s][i][j] + beta * C[i][j]; mirror: computed for
@@ -1083,28 +1112,36 @@ static int gemm_impl(Ctx* c, bool transA, bool transB, int M, int N, int K, doub
         gx = 2LL * c->num_cu;                          // a multiple of 8 (XCDs)
         if (gx % 8) { g.persist = 0; gx = nt; }
     }
-    dim3 grid((unsigned)gx, (unsigned)splits, (unsigned)o.batch);
+    unsigned gy = (unsigned)splits;
+    if (o.tag == 1 && g.diag_opt && g.xmap && c->syrk_persist && nt * splits > 2LL * c->num_cu && nt * splits < (1LL << 30) &&
+        (2 * c->num_cu) % 8 == 0) {
+        g.persist = (int)(nt * splits);
+        gx = 2LL * c->num_cu;
+        gy = 1;
+    }
+    dim3 grid((unsigned)gx, gy, (unsigned)o.batch);
     // op(A) is M x K: not transposed -> stored [M][K] (m-major); transposed -> stored [K][M] (k-major)
     const bool akm = transA;
     // op(B) is K x N: not transposed -> stored [K][N] (k-major); transposed -> stored [N][K]
     const bool bkm = !transB;
 #ifdef EDRGP_TILE_STAMPS
     static unsigned long long* stamp_dev = nullptr;
-    const size_t stamp_bytes = (size_t)nt * 6 * sizeof(unsigned long long);
-    if (o.tag == 2 && g.fuse_on && getenv("EDRGP_TILE_STAMPS_FILE") != nullptr) {
+        const bool stamp_phi = (o.tag == 1 && getenv("EDRGP_TILE_STAMPS_PHI") != nullptr);
+    const size_t stamp_count = stamp_phi ? (size_t)nt * splits : (size_t)nt;
+    if (((o.tag == 2 && g.fuse_on) || stamp_phi) && getenv("EDRGP_TILE_STAMPS_FILE") != nullptr) {
         if (stamp_dev == nullptr) HIP_TRY(hipMalloc(&stamp_dev, 64u << 20));
-        if (stamp_bytes <= (64u << 20)) { HIP_TRY(hipMemsetAsync(stamp_dev, 0, stamp_bytes, c->stream)); g.stamps = stamp_dev; }
+        if (stamp_count * 48 <= (64u << 20)) { HIP_TRY(hipMemsetAsync(stamp_dev, 0, stamp_count * 48, c->stream)); g.stamps = stamp_dev; }
     }
 #endif
     if (tile == 128) launch_variant<128, 128>(akm, bkm, o.tag, grid, c->stream, g, (unsigned)o.dyn_lds);
     else launch_variant<64, 64>(akm, bkm, o.tag, grid, c->stream, g, (unsigned)(o.dyn_lds ? o.dyn_lds : c->gemm_pad_now));
     HIP_TRY(hipGetLastError());
 #ifdef EDRGP_TILE_STAMPS
-    if (o.tag == 2 && g.stamps == stamp_dev && stamp_dev != nullptr) {       // every launch overwrites the file: the last one stays
-        std::vector<unsigned long long> hst((size_t)nt * 6);
+    if ((o.tag == 2 || stamp_phi) && g.stamps == stamp_dev && stamp_dev != nullptr) {       // every launch overwrites the file: the last one stays
+        std::vector<unsigned long long> hst(stamp_count * 6);
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(hst.data(), stamp_dev, stamp_bytes, hipMemcpyDeviceToHost));
-        if (FILE* fp = fopen(getenv("EDRGP_TILE_STAMPS_FILE"), "wb")) { fwrite(hst.data(), 1, stamp_bytes, fp); fclose(fp); }
+        HIP_TRY(hipMemcpy(hst.data(), stamp_dev, stamp_count * 48, hipMemcpyDeviceToHost));
+        if (FILE* fp = fopen(getenv("EDRGP_TILE_STAMPS_FILE"), "wb")) { fwrite(hst.data(), 1, stamp_count * 48, fp); fclose(fp); }
     }
 #endif
     return EDRGP_OK;
