@@ -25,7 +25,8 @@ if VARIANT:
     LIB = os.path.join(HERE, "libedrgp_hip_%s.so" % VARIANT)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result",
-         "-I/opt/rocm/include"] + ({"stamps": ["-DEDRGP_TILE_STAMPS"]}.get(VARIANT, []))
+         "-I/opt/rocm/include"] + ({"stamps": ["-DEDRGP_TILE_STAMPS"], "nol": ["-DEDRGP_NO_LAUNDER_T1"], "nopipe": ["-DEDRGP_FRAG_PIPE=0"], "pipe1": ["-DEDRGP_FRAG_PIPE=1"],
+                                      "nolp": ["-DEDRGP_NO_LAUNDER_T1", "-DEDRGP_NO_PERSIST_T1"]}.get(VARIANT, []))
 
 
 def _stale(target, deps):

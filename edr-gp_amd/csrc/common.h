@@ -252,6 +252,7 @@ struct Ctx {
     int side_gemm_pad = 0;            // see gemm_pad_now
     int gemm_pad_now = 0;             // dynamic LDS padding of the 64 x 64 products queued beside a factorisation (bytes)
     int kmm_early = 1;                // Kmm-term products that need A only run beside the factorisation of B
+    bool syrk_shares_gpu = false;     // set while the row pass is queued beside phase 1 (a persistent grid would starve it)
     int syrk_persist = 1;             // Phi launch as a persistent grid (la_gemm.hip)
     int gemm_persist = 1;             // gradient contraction as a persistent grid (la_gemm.hip)
     int gemm_alias = 0;               // timing probe of the contraction (wrong results): la_gemm.hip dbg_alias

@@ -43,6 +43,9 @@ constexpr int LPAD = 16;
 // 64 banks) is conflict-free there, so m-major images are read through a volatile LDS pointer, which the load /
 // store optimiser never merges and the scheduler still treats as an ordinary load (C2 bound+gradients -1.3 %,
 // Cm -0.2 %: the conflicts were not what holds the contraction at 59 TFLOP/s).
+#ifndef EDRGP_FRAG_PIPE
+#define EDRGP_FRAG_PIPE 2
+#endif
 template <bool VOL>
 __device__ __forceinline__ double frag_read(const double* p) {
     if (VOL) {
@@ -399,6 +402,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     constexpr bool EARLY_STORE = (BM == 128);      // long MFMA phase: stage the next tile mid-phase
     // m-major operand images (row stride 18 doubles) are read with unmerged ds_read_b64 (frag_read): 128-wide tiles
     constexpr bool VOL_FRAG = (EDRGP_UNMERGED_MMAJOR_READS != 0) && BM == 128 && BN == 128;
+    constexpr bool FRAG_PIPE = (EDRGP_FRAG_PIPE != 0) && BM == 128 && BN == 128 && (TAG == 1 || TAG == 9 || (TAG == 2 && EDRGP_FRAG_PIPE >= 2));
     typedef TileLoader<BM, AKM> LA;
     typedef TileLoader<BN, BKM> LB;
     __shared__ __attribute__((aligned(16))) double As[2][LA::SIZE];
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         const int w = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + in;
         split = w / nt;
         t = w - split * nt;
-    } else if (g.interleave >= 2) {
+    } else if (TAG == 0 && g.interleave >= 2) {
         // one triangular operand, full output: tiles ranked by k-range (longest first) and dealt to the CUs in a
         // snake -- pass 0 over the CUs ascending, pass 1 descending, ... -- so the workgroups sharing a CU have the same
         // total.  Assumes the dispatcher's order (workgroup b -> XCD b % 8, CU (b / 8) % 32 of it, slot b / 256); any
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         const int b = blockIdx.x, x = b & 7, l = b >> 3, cu = l & 31, slot = l >> 5;
         const int G = cu * 8 + x;
         t = slot * 256 + ((slot & 1) ? 255 - G : G);
-    } else if (g.interleave) {
+    } else if (TAG == 0 && g.interleave) {
         // zero-skipping products: a tile's k-range grows (or shrinks) with its index, so a contiguous eighth per XCD
         // hands one XCD twice the mean work and another almost none; dealt round-robin every XCD (and, 32 tiles apart,
         // every CU) gets the same mix
@@ -480,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         const int half = (g.tiles_n + 1) / 2;
         ti = t / half;
         tj = g.tiles_n - 1 - (t - ti * half);          // the long column tile first, its short partner second
-    } else if (g.interleave >= 2) {
+    } else if (TAG == 0 && g.interleave >= 2) {
         const int km = g.interleave >> 1;              // the single k-range restriction this product has
         if (km == 1)      { ti = g.tiles_m - 1 - t / g.tiles_n; tj = t % g.tiles_n; }      // k <= row end: last rows longest
         else if (km == 2) { ti = t / g.tiles_n; tj = t % g.tiles_n; }                        // k >= row start: first rows
@@ -504,7 +508,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     // MFMAs per k-step against 16): mean residency 484 of 512 (tools/phi_stamps.py).  Units in (split, tile) order, an
     // XCD's contiguous eighth 64 at a time: at most one diagonal-pair unit per workgroup.
     int p_start = 0, p_len = 0, p_per = 1, p_in = 0;
-    if ((TAG == 2 || TAG == 1) && g.persist) {
+#ifdef EDRGP_NO_PERSIST_T1
+    constexpr bool T1P = false;
+#else
+    constexpr bool T1P = (TAG == 1);
+#endif
+    if ((TAG == 2 || T1P) && g.persist) {
         const int total = g.persist;
         const int q = total >> 3, r = total & 7, x = (int)blockIdx.x & 7;
         p_in = (int)blockIdx.x >> 3;
@@ -515,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     }
 #pragma clang loop unroll(disable)
     for (int pass = 0; pass < npass; ++pass) {
-    if (TAG == 1 && g.persist) {
+    if (T1P && g.persist) {
         const int w = p_start + pass * p_per + p_in;
         const int per_split = g.persist / g.splits;
         split = w / per_split;
@@ -549,7 +558,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     // the loaders and the epilogue is hoisted out of the tile loop of a persistent launch and kept alive across it
     // (249 -> 256 VGPRs + 164 B of scratch per lane).
     int tid_l = tid0;
+#ifdef EDRGP_NO_LAUNDER_T1
+    if (TAG == 2 || TAG == 4) asm volatile("" : "+v"(tid_l));
+#else
     if (TAG == 1 || TAG == 2 || TAG == 4) asm volatile("" : "+v"(tid_l));
+#endif
     const int tid = tid_l;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -618,7 +631,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                           ((long long)(AKM ? BK : BM) * g.lda < (1LL << 28)) &&
                           ((long long)(BKM ? BK : BN) * g.ldb < (1LL << 28));
         unsigned offA[TileLoader<BM, AKM>::NV], offB[TileLoader<BN, BKM>::NV];
-        const int m0l = (g.dbg_alias & 1) ? m0 % (4 * BM) : m0, n0l = (g.dbg_alias & 2) ? 0 : n0;
+        const int m0l = (TAG == 2 && (g.dbg_alias & 1)) ? m0 % (4 * BM) : m0, n0l = (TAG == 2 && (g.dbg_alias & 2)) ? 0 : n0;
         const char* baseA = reinterpret_cast<const char*>(A + TileLoader<BM, AKM>::tile_origin(g.lda, m0l, kt0));
         const char* baseB = reinterpret_cast<const char*>(B + TileLoader<BN, BKM>::tile_origin(g.ldb, n0l, kt0));
         const long long stepA = TileLoader<BM, AKM>::tile_step(g.lda), stepB = TileLoader<BN, BKM>::tile_step(g.ldb);
@@ -668,6 +681,50 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
             // partner wave's MFMA stream cannot starve them; 4: the reverse (T5 style)
             if (g.dephase == 3) __builtin_amdgcn_s_setprio(0);
             if (g.dephase == 4) __builtin_amdgcn_s_setprio(2);
+            if constexpr (FRAG_PIPE) {
+                // Fragments of k-step kk + 1 are read while the MFMAs of step kk issue: written out as a two-stage
+                // register pipeline and pinned with scheduling groups (one LDS read after every second MFMA), because
+                // the scheduler's own choice flips with unrelated code changes between this order and "all reads after
+                // the last MFMA, then wait" (1 % of the Phi launch, seen in the ISA of two builds).
+                double a[2][TM], b[2][TN];
+#pragma unroll
+                for (int x = 0; x < TM; ++x) a[0][x] = frag_read<VOL_FRAG && !AKM>(&As[buf][LA::idx(lq, wm * WM + x * 16 + lr)]);
+#pragma unroll
+                for (int x = 0; x < TN; ++x) b[0][x] = frag_read<VOL_FRAG && !BKM>(&Bs[buf][LB::idx(lq, wn * WN + x * 16 + lr)]);
+#pragma unroll
+                for (int kk = 0; kk < BK / 4; ++kk) {
+                    const int cur = kk & 1, nxt = cur ^ 1;
+                    if (kk + 1 < BK / 4) {
+#pragma unroll
+                        for (int x = 0; x < TM; ++x)
+                            a[nxt][x] = frag_read<VOL_FRAG && !AKM>(&As[buf][LA::idx((kk + 1) * 4 + lq, wm * WM + x * 16 + lr)]);
+#pragma unroll
+                        for (int x = 0; x < TN; ++x)
+                            b[nxt][x] = frag_read<VOL_FRAG && !BKM>(&Bs[buf][LB::idx((kk + 1) * 4 + lq, wn * WN + x * 16 + lr)]);
+                    }
+#pragma unroll
+                    for (int x = 0; x < TM; ++x)
+#pragma unroll
+                        for (int y = 0; y < TN; ++y)
+                            acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][x], b[cur][y], acc[x][y], 0, 0, 0);
+                    if (kk + 1 < BK / 4) {
+#pragma unroll
+                        for (int i = 0; i < TM + TN; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);        // 2 MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // 1 LDS read
+                        }
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);          // the rest of this step's MFMAs
+                    if (EARLY_STORE && kk == BK / 4 - 2) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (more) {
+                            la.store(As[buf ^ 1], tid);
+                            lb.store(Bs[buf ^ 1], tid);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else
             {
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) {
@@ -1113,7 +1170,8 @@ static int gemm_impl(Ctx* c, bool transA, bool transB, int M, int N, int K, doub
         if (gx % 8) { g.persist = 0; gx = nt; }
     }
     unsigned gy = (unsigned)splits;
-    if (o.tag == 1 && g.diag_opt && g.xmap && c->syrk_persist && nt * splits > 2LL * c->num_cu && nt * splits < (1LL << 30) &&
+    if (o.tag == 1 && g.diag_opt && g.xmap && c->syrk_persist && !c->syrk_shares_gpu && nt * splits >= 6LL * c->num_cu &&
+        nt * splits < (1LL << 30) &&
         (2 * c->num_cu) % 8 == 0) {
         g.persist = (int)(nt * splits);
         gx = 2LL * c->num_cu;

@@ -710,7 +710,10 @@ struct SparseEval {
         // (edrgp_set_inducing / edrgp_set_kernel do not wait): the side stream starts behind them
         HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
         if (beside_rows) {
-            TRY(phase2(false));
+            c->syrk_shares_gpu = true;
+            const int st2 = phase2(false);
+            c->syrk_shares_gpu = false;
+            if (st2 != EDRGP_OK) return st2;
             *rows_done = true;
             SideStream side(c);
             HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_fork, 0));
