@@ -18,15 +18,16 @@ LIB = os.path.join(HERE, "libedrgp_hip.so")
 SOURCES = ["api.hip", "sparse_eval.hip", "sweep_eval.hip", "ep_eval.hip", "la_gemm.hip", "la_gemm32.hip", "la_chol.hip", "la_vec.hip", "gp_kernels.hip", "comm.hip", "calib.hip"]
 HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + \
           [os.path.join(HERE, "..", "include", "edrgp_hip.h")]
-# probe builds (never the product): EDRGP_BUILD_VARIANT=stamps -> libedrgp_hip_stamps.so with -DEDRGP_TILE_STAMPS
+# probe builds (never the product): EDRGP_BUILD_VARIANT=<name> -> libedrgp_hip_<name>.so; "stamps" adds
+# -DEDRGP_TILE_STAMPS, any other name takes its flags from EDRGP_VARIANT_FLAGS (e.g. "-DEDRGP_PIPE_M=2")
 VARIANT = os.environ.get("EDRGP_BUILD_VARIANT", "")
 if VARIANT:
     OBJ = os.path.join(HERE, "csrc", "_obj_" + VARIANT)
     LIB = os.path.join(HERE, "libedrgp_hip_%s.so" % VARIANT)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result",
-         "-I/opt/rocm/include"] + ({"stamps": ["-DEDRGP_TILE_STAMPS"], "nol": ["-DEDRGP_NO_LAUNDER_T1"], "nopipe": ["-DEDRGP_FRAG_PIPE=0"], "pipe1": ["-DEDRGP_FRAG_PIPE=1"],
-                                      "nolp": ["-DEDRGP_NO_LAUNDER_T1", "-DEDRGP_NO_PERSIST_T1"]}.get(VARIANT, []))
+         "-I/opt/rocm/include"] + ({"stamps": ["-DEDRGP_TILE_STAMPS"]}.get(VARIANT, []) if VARIANT else []) + \
+        os.environ.get("EDRGP_VARIANT_FLAGS", "").split()
 
 
 def _stale(target, deps):

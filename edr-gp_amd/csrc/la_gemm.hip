@@ -46,6 +46,9 @@ constexpr int LPAD = 16;
 #ifndef EDRGP_FRAG_PIPE
 #define EDRGP_FRAG_PIPE 2
 #endif
+#ifndef EDRGP_PIPE_M
+#define EDRGP_PIPE_M 4          // Phi: MFMAs between two fragment reads of the next k-step (1: 6.39, 2: 6.32, 3: 6.38, 4: 6.29 ms)
+#endif
 template <bool VOL>
 __device__ __forceinline__ double frag_read(const double* p) {
     if (VOL) {
@@ -402,6 +405,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     constexpr bool EARLY_STORE = (BM == 128);      // long MFMA phase: stage the next tile mid-phase
     // m-major operand images (row stride 18 doubles) are read with unmerged ds_read_b64 (frag_read): 128-wide tiles
     constexpr bool VOL_FRAG = (EDRGP_UNMERGED_MMAJOR_READS != 0) && BM == 128 && BN == 128;
+    constexpr int PIPE_M = (TAG == 2) ? 2 : EDRGP_PIPE_M;          // the contraction has 6 read instructions per k-step, Phi 4
     constexpr bool FRAG_PIPE = (EDRGP_FRAG_PIPE != 0) && BM == 128 && BN == 128 && (TAG == 1 || TAG == 9 || (TAG == 2 && EDRGP_FRAG_PIPE >= 2));
     typedef TileLoader<BM, AKM> LA;
     typedef TileLoader<BN, BKM> LB;
@@ -710,7 +714,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                     if (kk + 1 < BK / 4) {
 #pragma unroll
                         for (int i = 0; i < TM + TN; ++i) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);        // 2 MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x008, PIPE_M, 0);         // MFMAs
                             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // 1 LDS read
                         }
                     }
