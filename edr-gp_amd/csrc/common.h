@@ -184,6 +184,8 @@ int grad_elementwise(Ctx* c, const KSpec& ks, int part, const double* X, const d
 int build_xtilde(Ctx* c, const double* X, int64_t rows, int D, double* Xt);
 int build_xq(Ctx* c, const double* X, int64_t rows, int D, double* Xq);               // [X | X.^2]
 int assemble_gt(Ctx* c, const double* G2, const double* cs, int M, int D, double beta_acc, double* Gt);
+int grad_finish(Ctx* c, int np, int M, int Mr, int D, const double* gt_nm, const double* gt_mm, const double* Z,
+                const double* invl, double* dZ, double* spart, int* nblocks);
 int sum_into(Ctx* c, const double* part, int n, double* accum);   // accum[0] += sum(part), fixed order
 int rowdot(Ctx* c, const double* A, const double* B, int64_t rows, int cols, int ld, double* out);
 // posterior mean / latent variance / mean Jacobian for one device-resident row chunk
@@ -248,6 +250,7 @@ struct Ctx {
     int dbg_gemm_kmode = 0, dbg_gemm_tri = 0, dbg_gemm_tile = 0, dbg_gemm_reps = 1;   // edrgp_dbg_gemm only
     int mid_split = 4;                // k-segments of lower-tiles-only products over triangular operands (la_gemm.hip)
     int gemm_interleave = 2;          // zero-skipping products: 1 tiles dealt round-robin to the XCDs, 2 also length-ranked snake over the CUs (la_gemm.hip)
+    int grad_finish_dev = 1;          // finish dZ / d lengthscale on the device (sparse_eval.hip)
     int skinny_split = 1;             // split-K for skinny outputs with 64 <= k-tiles < 256 (la_gemm.hip)
     int side_gemm_pad = 0;            // see gemm_pad_now
     int gemm_pad_now = 0;             // dynamic LDS padding of the 64 x 64 products queued beside a factorisation (bytes)
@@ -315,6 +318,7 @@ struct Ctx {
     DBuf mats[16];                    // M x M (or N x N dense) matrices
     DBuf ptw;                         // -diag(wv) [P | 1 | P.^2] of the RBF predict-gradient path
     bool knm_train_valid = false;     // c->Knm holds K(X, Z) of ALL training rows for the current theta / Z
+    DBuf gfin;                        // dZ (Mr x D) and per-block partial sums of the length-scale terms (grad_finish)
     DBuf g2;                          // T^T [X | X.^2] and column sums of T (fused gradient path)
     DBuf slabs, bpart, scal, info, gt_nm, gt_mm, tmpvec[6], panel, trtri_ws, dinv, red, lbaug;
     DBuf pack;                        // lower triangle of Phi and b, packed for the all-reduce

@@ -413,6 +413,62 @@ int assemble_gt(Ctx* c, const double* G2, const double* cs, int M, int D, double
     return EDRGP_OK;
 }
 
+// Finishing of the sparse gradients on the device: dZ and the per-block partial sums of the length-scale terms out of
+// the three M x (2D+1) tables [T^T X | colsum T | T^T X.^2] of every part (row-pass table, Kmm term transposed and
+// not).  Saves the 3.2 MB device -> host copy of the tables at Cm and the host's pass over freshly DMA-ed memory
+// (0.2 ms per evaluation).  Block = 64 x 4 threads over 32 rows; sums over rows in a fixed order.
+//   s[p][q]  = sum_m  gn[D+1+q] + cn z^2 - 2 z gn[q]  +  gt[D+1+q] + ct z^2 - 2 z gt[q]
+//   dZ[m][q] = sum_p invl2[p][q] ((z cn - gn[q]) + (z ct - gt[q]) + (z cN - gN[q]))
+constexpr int GF_ROWS = 32;
+__global__ __launch_bounds__(256) void grad_finish_kernel(int np, int M, int Mr, int D, const double* __restrict__ gt_nm,
+                                                         const double* __restrict__ gt_mm, const double* __restrict__ Z,
+                                                         const double* __restrict__ invl, double* __restrict__ dZ,
+                                                         double* __restrict__ spart) {
+    __shared__ double sh[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int Wd = 2 * D + 1;
+    const int m0 = blockIdx.x * GF_ROWS;
+    for (int q0 = 0; q0 < D; q0 += 64) {
+        const int q = q0 + tx;
+        for (int p = 0; p < np; ++p) {
+            const double* Gn = gt_nm + (size_t)p * M * Wd;
+            const double* GT = gt_mm + (size_t)(2 * p) * M * Wd;
+            const double* GN = gt_mm + (size_t)(2 * p + 1) * M * Wd;
+            double s = 0.0;
+            if (q < D) {
+                const double il = invl[(size_t)p * D + q], il2 = il * il;
+                for (int r = ty; r < GF_ROWS; r += 4) {
+                    const int m = m0 + r;
+                    if (m >= Mr) break;
+                    const double* gn = Gn + (size_t)m * Wd;
+                    const double* gt = GT + (size_t)m * Wd;
+                    const double* gN = GN + (size_t)m * Wd;
+                    const double z = Z[(size_t)m * D + q];
+                    const double cn = gn[D], ct = gt[D], cN = gN[D];
+                    s += (gn[D + 1 + q] + cn * z * z - 2.0 * z * gn[q]) + (gt[D + 1 + q] + ct * z * z - 2.0 * z * gt[q]);
+                    const double d = il2 * ((z * cn - gn[q]) + (z * ct - gt[q]) + (z * cN - gN[q]));
+                    double* o = dZ + (size_t)m * D + q;
+                    *o = (p == 0) ? d : *o + d;
+                }
+            }
+            sh[ty][tx] = s;
+            __syncthreads();
+            if (ty == 0 && q < D) spart[((size_t)blockIdx.x * np + p) * D + q] = (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
+            __syncthreads();
+        }
+    }
+}
+
+int grad_finish(Ctx* c, int np, int M, int Mr, int D, const double* gt_nm, const double* gt_mm, const double* Z,
+                const double* invl, double* dZ, double* spart, int* nblocks) {
+    const int nb = (Mr + GF_ROWS - 1) / GF_ROWS;
+    *nblocks = nb;
+    hipLaunchKernelGGL(grad_finish_kernel, dim3((unsigned)nb), dim3(256), 0, c->stream, np, M, Mr, D, gt_nm, gt_mm, Z, invl,
+                       dZ, spart);
+    HIP_TRY(hipGetLastError());
+    return EDRGP_OK;
+}
+
 int build_xtilde(Ctx* c, const double* X, int64_t rows, int D, double* Xt) {
     const int64_t total = rows * (2 * D + 1);
     const int nb = (int)std::min<int64_t>(4096, (total + 255) / 256);

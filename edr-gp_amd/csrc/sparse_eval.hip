@@ -112,6 +112,8 @@ struct SparseEval {
     bool prebuilt = false;        // K_nm (and b) of the single row chunk were built beside phase 1
     bool kmmi_done = false;       // Kmm^-1 = Li^T Li was formed on the side stream
     bool kmmi_pending = false;    // ... and the main stream has not waited for it yet
+    bool fin_dev = false;         // dZ / d lengthscale finished on the device (grad_finish)
+    int fin_blocks = 0;
     bool tma_done = false;        // Lm^-T A Lm^-1 (Kmm term) was formed on the side stream beside the factorisation of B
     bool k32_resident = false;
     // precision 32 asks for the fp32 row pass; it is used while the Gram form is safe in fp32 (error ~ eps32
@@ -628,6 +630,7 @@ struct SparseEval {
         // pinned host staging owned by the context (no per-evaluation allocation / zero-fill; true async copies);
         // Z itself is the host copy kept by edrgp_set_inducing
         const size_t n_nm = (size_t)np * M * Wd, n_mm = (size_t)2 * np * M * Wd;
+        fin_dev = c->grad_finish_dev != 0;
         if (c->h_stage_cap < n_nm + n_mm) {
             if (c->h_stage) (void)hipHostFree(c->h_stage);
             c->h_stage = nullptr;
@@ -635,8 +638,18 @@ struct SparseEval {
             HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_stage), (n_nm + n_mm) * sizeof(double), hipHostMallocDefault));
             c->h_stage_cap = n_nm + n_mm;
         }
-        HIP_TRY(hipMemcpyAsync(c->h_stage, c->gt_nm.d(), n_nm * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->h_stage + n_nm, c->gt_mm.d(), n_mm * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (fin_dev) {
+            // dZ and the length-scale partial sums leave the device instead of the three tables
+            const size_t n_dz = (size_t)Mr * D;
+            const size_t n_sp = (size_t)((Mr + 31) / 32) * np * D;
+            TRY(c->gfin.reserve((n_dz + n_sp) * sizeof(double)));
+            TRY(grad_finish(c, np, M, Mr, D, c->gt_nm.d(), c->gt_mm.d(), c->Z.d(), c->invl.d(), c->gfin.d(), c->gfin.d() + n_dz,
+                            &fin_blocks));
+            HIP_TRY(hipMemcpyAsync(c->h_stage, c->gfin.d(), (n_dz + n_sp) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        } else {
+            HIP_TRY(hipMemcpyAsync(c->h_stage, c->gt_nm.d(), n_nm * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->h_stage + n_nm, c->gt_mm.d(), n_mm * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        }
         tr.mark("grad D2H queued");
         TRY(fetch());
         c->drain_events();
@@ -656,6 +669,20 @@ struct SparseEval {
         out->dlen.assign((size_t)np * D, 0.0);
         out->dZ.assign((size_t)Mr * D, 0.0);
         std::vector<double> s_acc((size_t)D), il2v((size_t)D);
+        if (fin_dev) {
+            const size_t n_dz = (size_t)Mr * D;
+            const double* sp = c->h_stage + n_dz;
+            std::memcpy(out->dZ.data(), c->h_stage, n_dz * sizeof(double));
+            for (int p = 0; p < np; ++p) {
+                out->dvar[p] = h_sc[SC_DVAR_NM + p] + h_sc[SC_DVAR_MM + p] - 0.5 * beta * gl.N;   // + sum dL_dKdiag
+                for (int q = 0; q < D; ++q) {
+                    double acc = 0.0;
+                    for (int b = 0; b < fin_blocks; ++b) acc += sp[((size_t)b * np + p) * D + q];     // fixed order
+                    const double l = c->lens[(size_t)p * D + q];
+                    out->dlen[(size_t)p * D + q] = -(1.0 / (l * l) / l) * acc;
+                }
+            }
+        } else
         for (int p = 0; p < np; ++p) {
             out->dvar[p] = h_sc[SC_DVAR_NM + p] + h_sc[SC_DVAR_MM + p] - 0.5 * beta * gl.N;   // + sum dL_dKdiag
             const double* Gn = &g_nm[(size_t)p * M * Wd];
@@ -668,19 +695,22 @@ struct SparseEval {
             }
             // rows of the M x (2D+1) tables are walked once (m outer, q inner); every per-q sum still runs over
             // m in ascending order, so the result is the one of the q-outer form
+            double* __restrict__ sa = s_acc.data();
+            const double* __restrict__ il2 = il2v.data();
             for (int m = 0; m < Mr; ++m) {            // phantom rows of the tables are zero
-                const double* gn = Gn + (size_t)m * Wd;
-                const double* gt = GmT + (size_t)m * Wd;
-                const double* gN = GmN + (size_t)m * Wd;
-                const double* zr = &Zh[(size_t)m * D];
-                double* dz = &out->dZ[(size_t)m * D];
+                const double* __restrict__ gn = Gn + (size_t)m * Wd;
+                const double* __restrict__ gt = GmT + (size_t)m * Wd;
+                const double* __restrict__ gN = GmN + (size_t)m * Wd;
+                const double* __restrict__ zr = &Zh[(size_t)m * D];
+                double* __restrict__ dz = &out->dZ[(size_t)m * D];
                 const double cn = gn[D], ct = gt[D], cN = gN[D];
+#pragma clang loop vectorize(enable) interleave(enable)
                 for (int q = 0; q < D; ++q) {
                     const double z = zr[q];
                     double s_nm = gn[D + 1 + q] + cn * z * z - 2.0 * z * gn[q];
                     double s_mm = gt[D + 1 + q] + ct * z * z - 2.0 * z * gt[q];
-                    s_acc[q] += s_nm + s_mm;
-                    dz[q] += il2v[q] * ((z * cn - gn[q]) + (z * ct - gt[q]) + (z * cN - gN[q]));
+                    sa[q] += s_nm + s_mm;
+                    dz[q] += il2[q] * ((z * cn - gn[q]) + (z * ct - gt[q]) + (z * cN - gN[q]));
                 }
             }
             for (int q = 0; q < D; ++q) out->dlen[(size_t)p * D + q] = -(il2v[q] / c->lens[(size_t)p * D + q]) * s_acc[q];
