@@ -44,7 +44,7 @@ constexpr int LPAD = 16;
 // store optimiser never merges and the scheduler still treats as an ordinary load (C2 bound+gradients -1.3 %,
 // Cm -0.2 %: the conflicts were not what holds the contraction at 59 TFLOP/s).
 #ifndef EDRGP_FRAG_PIPE
-#define EDRGP_FRAG_PIPE 2
+#define EDRGP_FRAG_PIPE 3
 #endif
 #ifndef EDRGP_PIPE_M
 #define EDRGP_PIPE_M 4          // Phi: MFMAs between two fragment reads of the next k-step (1: 6.39, 2: 6.32, 3: 6.38, 4: 6.29 ms)
@@ -405,8 +405,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     constexpr bool EARLY_STORE = (BM == 128);      // long MFMA phase: stage the next tile mid-phase
     // m-major operand images (row stride 18 doubles) are read with unmerged ds_read_b64 (frag_read): 128-wide tiles
     constexpr bool VOL_FRAG = (EDRGP_UNMERGED_MMAJOR_READS != 0) && BM == 128 && BN == 128;
-    constexpr int PIPE_M = (TAG == 2) ? 2 : EDRGP_PIPE_M;          // the contraction has 6 read instructions per k-step, Phi 4
-    constexpr bool FRAG_PIPE = (EDRGP_FRAG_PIPE != 0) && BM == 128 && BN == 128 && (TAG == 1 || TAG == 9 || (TAG == 2 && EDRGP_FRAG_PIPE >= 2));
+    constexpr int PIPE_M = (BM != 128) ? 1 : ((TAG == 2) ? 2 : EDRGP_PIPE_M);   // the contraction has 6 read instructions per k-step, Phi 4
+    constexpr bool FRAG_PIPE = (EDRGP_FRAG_PIPE != 0) && ((BM == 128 && BN == 128 && (TAG == 1 || TAG == 9 || (TAG == 2 && EDRGP_FRAG_PIPE >= 2))) ||
+                                                           (EDRGP_FRAG_PIPE >= 3 && BM == 64 && BN == 64));
     typedef TileLoader<BM, AKM> LA;
     typedef TileLoader<BN, BKM> LB;
     __shared__ __attribute__((aligned(16))) double As[2][LA::SIZE];
