@@ -7,8 +7,10 @@ from edrgp_amd.backend import HipGP
 kinds_all = ["RBF", "Matern32", "Matern52"]
 
 
-def run(h, seed=0, n_cases=60, modes=(0, 0, 1, 2), verbose=True):
-  """Returns the list of failing cases (empty = all within tolerance)."""
+def run(h, seed=0, n_cases=60, modes=(0, 0, 1, 2), verbose=True, large=False):
+  """Returns the list of failing cases (empty = all within tolerance).  ``large``: shapes that reach the persistent
+  grids, the k-segmented / length-ranked M x M x M products and the chunked row pass (N in the tens of thousands,
+  M beyond 1024, not multiples of the tile sizes); the oracle needs seconds per case there."""
   rng = np.random.default_rng(seed)
   bad = []
   for case in range(n_cases):
@@ -18,11 +20,17 @@ def run(h, seed=0, n_cases=60, modes=(0, 0, 1, 2), verbose=True):
       if case % 7 == 3:        # inducing sets beyond 256: phantom padding to a multiple of 128, the (M + 1)-row bound-only path
           M = int(rng.integers(257, 520))
           N = int(rng.integers(M, 1600))
+      if large:
+          M = int(rng.integers(1024, 2300))
+          N = int(rng.integers(max(20000, 28_000_000 // M), 52000))
+          D = int(rng.integers(2, 33)) if case % 3 else int(rng.integers(33, 65))
       nparts = 1 if rng.random() < 0.7 else 2
+      if large and case % 2 == 0:
+          nparts = 1                      # the fused gradient epilogue is the single-part path
       kinds = [kinds_all[int(rng.integers(0, 3))] for _ in range(nparts)]
       opts = [dict(variance=float(rng.uniform(0.3, 2.0)), lengthscale=float(rng.uniform(0.8, 3.0) * np.sqrt(D))) for _ in range(nparts)]
       noise = float(10 ** rng.uniform(-2, 0))
-      chunk = int(rng.choice([64, 100, 257, 131072]))
+      chunk = int(rng.choice([64, 100, 257, 131072])) if not large else int(rng.choice([16384, 30000, 131072, 131072]))
       mode = int(rng.choice(list(modes)))
       X, y, Z = go.synthetic_problem(N, D, M, seed=1000 + case)
       kern = go.make_kernel(kinds, D, opts)
@@ -73,5 +81,5 @@ def run(h, seed=0, n_cases=60, modes=(0, 0, 1, 2), verbose=True):
 if __name__ == "__main__":
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-    failing = run(HipGP(0), seed, n)
+    failing = run(HipGP(0), seed, n, large=len(sys.argv) > 3 and sys.argv[3] == "large")
     print("fuzz: %d cases, %d outside tolerance" % (n, len(failing)))

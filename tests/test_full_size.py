@@ -218,3 +218,15 @@ def test_c4_full_size_batched_sweep(hip, dc):
         kern = go.make_kernel(["RBF"], dc, [dict(variance=1.0, lengthscale=scales[g])])
         ref = float(go.vardtc_inference(kern, Xp, Xp[Zr], 0.01, y[:, None])["log_marginal"][0, 0])
         assert abs(bat[g]["bound"] - ref) <= 1e-10 * abs(ref), (g, bat[g]["bound"], ref)
+
+
+@pytest.mark.gpu
+def test_random_large_shapes_against_oracle(hip):
+    """Shapes that reach the persistent grids of the two big launches, the k-segmented and length-ranked M x M x M
+    products and the chunked row pass: N in the tens of thousands, M in 1024..2300 and not a multiple of the tile sizes,
+    D up to 64, sum kernels, chunk_rows below N (tests/fuzz/fuzz.py, ``large``): bound, gradients, posterior mean /
+    variance / Jacobian against the oracle, tolerances scaled by cond(Kmm) as in the small-shape fuzzer."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz"))
+    import fuzz
+    assert fuzz.run(hip, seed=5, n_cases=3, modes=(0, 0, 2), verbose=True, large=True) == []
