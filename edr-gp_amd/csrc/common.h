@@ -257,7 +257,7 @@ struct Ctx {
     int kmm_early = 1;                // Kmm-term products that need A only run beside the factorisation of B
     bool syrk_shares_gpu = false;     // set while the row pass is queued beside phase 1 (a persistent grid would starve it)
     int syrk_persist = 1;             // Phi launch as a persistent grid (la_gemm.hip)
-    int gemm_persist = 1;             // gradient contraction as a persistent grid (la_gemm.hip)
+    int gemm_persist = 2;             // 1: gradient contraction as a persistent grid, 2: the stable form's product too (la_gemm.hip)
     int gemm_alias = 0;               // timing probe of the contraction (wrong results): la_gemm.hip dbg_alias
     int gemm_dephase = 3;             // see la_gemm.hip: 3 = staging / barrier phases at raised priority
     bool trace = false;

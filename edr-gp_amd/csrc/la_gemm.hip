@@ -518,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 #else
     constexpr bool T1P = (TAG == 1);
 #endif
-    if ((TAG == 2 || T1P) && g.persist) {
+    if ((TAG == 2 || TAG == 4 || T1P) && g.persist) {
         const int total = g.persist;
         const int q = total >> 3, r = total & 7, x = (int)blockIdx.x & 7;
         p_in = (int)blockIdx.x >> 3;
@@ -526,6 +526,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         p_start = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q);
         p_len = q + (x < r ? 1 : 0);
         npass = (p_len - p_in + p_per - 1) / p_per;
+        if (TAG == 4) npass *= 2;                      // a unit of the stable form's product = a pair of column tiles
     }
 #pragma clang loop unroll(disable)
     for (int pass = 0; pass < npass; ++pass) {
@@ -554,6 +555,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 #ifdef EDRGP_TILE_STAMPS
         ts_entry = __builtin_amdgcn_s_memrealtime();
 #endif
+    } else if (TAG == 4 && g.persist) {
+        // persistent stable-form product: units (row tile, column-tile pair) in an XCD's contiguous eighth, two
+        // passes per unit (the long column tile, then its short partner); 140 us units paid a 19 us turnover each
+        t = p_start + (pass >> 1) * p_per + p_in;
+        const int half = (g.tiles_n + 1) / 2;
+        ti = t / half;
+        const int tj_long = g.tiles_n - 1 - (t - ti * half);
+        const int tj_short = g.tiles_n - 1 - tj_long;
+        if ((pass & 1) && tj_short == tj_long) continue;               // the middle column of an odd count has no partner
+        tj = (pass & 1) ? tj_short : tj_long;
+        if (pass) __syncthreads();                     // the previous tile's epilogue is done with the LDS
     } else if (pass == 1) {
         tj = tj_second;
         __syncthreads();                               // the first tile's epilogue is done with the LDS
@@ -1169,7 +1181,8 @@ static int gemm_impl(Ctx* c, bool transA, bool transB, int M, int N, int K, doub
     // the gradient contraction with its fused epilogue runs as a persistent grid when it has more than three rounds of tiles
     g.persist = 0;
     long long gx = nt;
-    if (o.tag == 2 && g.fuse_on && tile == 128 && c->gemm_persist && nt > 6LL * c->num_cu && nt < (1LL << 30)) {
+    if (((o.tag == 2 && g.fuse_on) || (o.tag == 4 && g.pair && c->gemm_persist >= 2)) && tile == 128 && c->gemm_persist &&
+        nt > 6LL * c->num_cu && nt < (1LL << 30)) {
         g.persist = (int)nt;
         gx = 2LL * c->num_cu;                          // a multiple of 8 (XCDs)
         if (gx % 8) { g.persist = 0; gx = nt; }
