@@ -35,6 +35,7 @@ rng = np.random.default_rng(0)
 X = rng.standard_normal((N, D)); y = np.tanh(X @ (np.ones(D) / np.sqrt(D))) + 0.05 * rng.standard_normal(N)
 y = (y - y.mean()) / y.std()
 Zr = rng.permutation(N)[:M]
+projection_sweep(X, y, Zr, [np.linalg.qr(rng.standard_normal((D, D)))[0]], n_scales=16, want_gram=True, hip=h)   # workspaces (16 K_g kept: 26 GB) allocated once
 for c in (0, 32, 63):
     W = np.linalg.qr(rng.standard_normal((D, D - c)))[0]
     t0 = time.perf_counter()
