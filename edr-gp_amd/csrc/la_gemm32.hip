@@ -147,11 +147,15 @@ struct Loader32 {
 };
 
 // TAG: 0 plain store, 1 Phi syrk (symbol only), 2 gradient epilogue, 3 kernel-matrix epilogue
+#ifndef EDRGP_FRAG_PIPE32
+#define EDRGP_FRAG_PIPE32 1
+#endif
 template <int BM, int BN, bool AKM, bool BKM, int TAG>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(G32Args g) {
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int TM = WM / 16, TN = WN / 16;
     constexpr bool EARLY_STORE = (BM == 128);
+    constexpr bool FRAG_PIPE32 = (EDRGP_FRAG_PIPE32 != 0) && BM == 128 && BN == 128;
     typedef Loader32<BM, AKM> LA;
     typedef Loader32<BN, BKM> LB;
     __shared__ __attribute__((aligned(16))) float As[2][LA::SIZE];
@@ -235,6 +239,47 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(G32Args g) {
                 }
             }
             if (g.prio) __builtin_amdgcn_s_setprio(0);
+            if constexpr (FRAG_PIPE32) {
+                // fragments of k-step kk + 1 read under the MFMAs of step kk: the two-stage register pipeline of the
+                // fp64 kernels (la_gemm.hip), pinned with scheduling groups (fp32 contraction at config 5: -2.2 %;
+                // groups of 4 MFMAs instead of 2: +1 %)
+                float a[2][TM], b[2][TN];
+#pragma unroll
+                for (int x = 0; x < TM; ++x) a[0][x] = As[buf][LA::idx(lq, wm * WM + x * 16 + lr)];
+#pragma unroll
+                for (int x = 0; x < TN; ++x) b[0][x] = Bs[buf][LB::idx(lq, wn * WN + x * 16 + lr)];
+#pragma unroll
+                for (int kk = 0; kk < BK32 / 4; ++kk) {
+                    const int cur = kk & 1, nxt = cur ^ 1;
+                    if (kk + 1 < BK32 / 4) {
+#pragma unroll
+                        for (int x = 0; x < TM; ++x) a[nxt][x] = As[buf][LA::idx((kk + 1) * 4 + lq, wm * WM + x * 16 + lr)];
+#pragma unroll
+                        for (int x = 0; x < TN; ++x) b[nxt][x] = Bs[buf][LB::idx((kk + 1) * 4 + lq, wn * WN + x * 16 + lr)];
+                    }
+#pragma unroll
+                    for (int x = 0; x < TM; ++x)
+#pragma unroll
+                        for (int y = 0; y < TN; ++y)
+                            acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][x], b[cur][y], acc[x][y], 0, 0, 0);
+                    if (kk + 1 < BK32 / 4) {
+#pragma unroll
+                        for (int i = 0; i < TM + TN; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+                    if (EARLY_STORE && kk == BK32 / 4 - 2) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (more) {
+                            la.store(As[buf ^ 1], tid);
+                            lb.store(Bs[buf ^ 1], tid);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else
 #pragma unroll
             for (int kk = 0; kk < BK32 / 4; ++kk) {
                 float a[TM], b[TN];
