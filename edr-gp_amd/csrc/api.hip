@@ -376,6 +376,7 @@ int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
     else if (!std::strcmp(key, "kmm_early")) c->kmm_early = (int)value;
     else if (!std::strcmp(key, "side_gemm_pad")) c->side_gemm_pad = (int)value;
     else if (!std::strcmp(key, "skinny_split")) c->skinny_split = (int)value;
+    else if (!std::strcmp(key, "gemm_narrow")) c->gemm_narrow = (int)value;
     else if (!std::strcmp(key, "grad_finish_dev")) c->grad_finish_dev = (int)value;
     else if (!std::strcmp(key, "gemm_interleave")) c->gemm_interleave = (int)value;
     else if (!std::strcmp(key, "mid_split")) c->mid_split = (int)value;

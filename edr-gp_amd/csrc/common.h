@@ -251,6 +251,7 @@ struct Ctx {
     int mid_split = 4;                // k-segments of lower-tiles-only products over triangular operands (la_gemm.hip)
     int gemm_interleave = 2;          // zero-skipping products: 1 tiles dealt round-robin to the XCDs, 2 also length-ranked snake over the CUs (la_gemm.hip)
     int grad_finish_dev = 1;          // finish dZ / d lengthscale on the device (sparse_eval.hip)
+    int gemm_narrow = 1;              // 64 x 32 tiles for TN products with at most 32 columns (la_gemm.hip)
     int skinny_split = 1;             // split-K for skinny outputs with 64 <= k-tiles < 256 (la_gemm.hip)
     int side_gemm_pad = 0;            // see gemm_pad_now
     int gemm_pad_now = 0;             // dynamic LDS padding of the 64 x 64 products queued beside a factorisation (bytes)

@@ -1158,8 +1158,11 @@ static int gemm_impl(Ctx* c, bool transA, bool transB, int M, int N, int K, doub
         if (c->red2.reserve(256) != EDRGP_OK) return EDRGP_ERR_HIP;
         g.stamps = static_cast<unsigned long long*>(c->red2.p);
     }
+    // narrow outputs (T^T [X | X.^2] with 2D <= 32 columns, ...): a 64 x 32 tile -- the 64 x 64 tile would spend half its
+    // MFMAs on padding (N = 100000, M = 2048: 496 -> 282 us for 32 columns)
+    const bool narrow = (tile == 64 && N <= 32 && o.tag == 0 && !o.tri && o.kmode == 0 && transA && !transB && c->gemm_narrow);
     g.tiles_m = (M + tile - 1) / tile;
-    g.tiles_n = (N + tile - 1) / tile;
+    g.tiles_n = narrow ? 1 : (N + tile - 1) / tile;
     g.vecA = aligned16(A) && (lda % 2 == 0) && (o.strideA % 2 == 0);
     g.vecB = aligned16(B) && (ldb % 2 == 0) && (o.strideB % 2 == 0);
     if (slab != nullptr) {
@@ -1209,7 +1212,8 @@ static int gemm_impl(Ctx* c, bool transA, bool transB, int M, int N, int K, doub
         if (stamp_count * 48 <= (64u << 20)) { HIP_TRY(hipMemsetAsync(stamp_dev, 0, stamp_count * 48, c->stream)); g.stamps = stamp_dev; }
     }
 #endif
-    if (tile == 128) launch_variant<128, 128>(akm, bkm, o.tag, grid, c->stream, g, (unsigned)o.dyn_lds);
+    if (narrow) hipLaunchKernelGGL((gemm_f64_kernel<64, 32, true, true, 0>), grid, dim3(256), 0, c->stream, g);
+    else if (tile == 128) launch_variant<128, 128>(akm, bkm, o.tag, grid, c->stream, g, (unsigned)o.dyn_lds);
     else launch_variant<64, 64>(akm, bkm, o.tag, grid, c->stream, g, (unsigned)(o.dyn_lds ? o.dyn_lds : c->gemm_pad_now));
     HIP_TRY(hipGetLastError());
 #ifdef EDRGP_TILE_STAMPS
