@@ -405,8 +405,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     constexpr bool EARLY_STORE = (BM == 128);      // long MFMA phase: stage the next tile mid-phase
     // m-major operand images (row stride 18 doubles) are read with unmerged ds_read_b64 (frag_read): 128-wide tiles
     constexpr bool VOL_FRAG = (EDRGP_UNMERGED_MMAJOR_READS != 0) && BM == 128 && BN == 128;
-    constexpr int PIPE_M = (BM != 128) ? 1 : ((TAG == 2) ? 2 : EDRGP_PIPE_M);   // the contraction has 6 read instructions per k-step, Phi 4
-    constexpr bool FRAG_PIPE = (EDRGP_FRAG_PIPE != 0) && ((BM == 128 && BN == 128 && (TAG == 1 || TAG == 9 || (TAG == 2 && EDRGP_FRAG_PIPE >= 2))) ||
+    constexpr bool T25 = (TAG == 2 || TAG == 5);      // gradient contraction: 2 = RBF epilogue (k from the resident K_nm), 5 = distance-recomputing epilogue
+    constexpr int PIPE_M = (BM != 128) ? 1 : (T25 ? 2 : EDRGP_PIPE_M);   // the contraction has 6 read instructions per k-step, Phi 4
+    constexpr bool FRAG_PIPE = (EDRGP_FRAG_PIPE != 0) && ((BM == 128 && BN == 128 && (TAG == 1 || TAG == 9 || (T25 && EDRGP_FRAG_PIPE >= 2))) ||
                                                            (EDRGP_FRAG_PIPE >= 3 && BM == 64 && BN == 64));
     typedef TileLoader<BM, AKM> LA;
     typedef TileLoader<BN, BKM> LB;
@@ -518,7 +519,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 #else
     constexpr bool T1P = (TAG == 1);
 #endif
-    if ((TAG == 2 || TAG == 4 || T1P) && g.persist) {
+    if ((TAG == 2 || TAG == 5 || TAG == 4 || T1P) && g.persist) {
         const int total = g.persist;
         const int q = total >> 3, r = total & 7, x = (int)blockIdx.x & 7;
         p_in = (int)blockIdx.x >> 3;
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
             ti = tj = pair_d0;
         }
         if (pass) __syncthreads();                     // the previous unit is done with the LDS
-    } else if (TAG == 2 && g.persist) {
+    } else if ((TAG == 2 || TAG == 5) && g.persist) {
         t = p_start + pass * p_per + p_in;
         ti = t / g.tiles_n;
         tj = t - ti * g.tiles_n;
@@ -576,9 +577,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     // (249 -> 256 VGPRs + 164 B of scratch per lane).
     int tid_l = tid0;
 #ifdef EDRGP_NO_LAUNDER_T1
-    if (TAG == 2 || TAG == 4) asm volatile("" : "+v"(tid_l));
+    if (TAG == 2 || TAG == 5 || TAG == 4) asm volatile("" : "+v"(tid_l));
 #else
-    if (TAG == 1 || TAG == 2 || TAG == 4) asm volatile("" : "+v"(tid_l));
+    if (TAG == 1 || TAG == 2 || TAG == 5 || TAG == 4) asm volatile("" : "+v"(tid_l));
 #endif
     const int tid = tid_l;
     const int lane = tid & 63, wave = tid >> 6;
@@ -842,7 +843,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     }
 
     // ---- fused gradient epilogue (TAG 2): T = (acc + ycoef y wv^T) .* h(r), sum Q .* k / var
-    if (TAG == 2 && g.fuse_on) {
+    if ((TAG == 2 || TAG == 5) && g.fuse_on) {
         // scaled inputs of this tile's rows / columns, staged in the (now idle) operand LDS:
         // Xs[q][BM] = X[m0 + i][q] * invl[q], Zs[q][BN] = Z[n0 + j][q] * invl[q]
         constexpr int DC = 32;                               // feature chunk
@@ -850,7 +851,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         double* Xs = &As[0][0];
         double* Zs = &Bs[0][0];
         const FuseT& f = g.fuse;
-        if (f.K != nullptr) {
+        if (TAG == 2) {
+            // (the host launches TAG 2 only with f.K set: one epilogue per kernel -- with both in one kernel the
+            // contraction sat at 254-256 VGPRs and 221 spilled SGPRs, alone the RBF one takes 234 / 56)
             // RBF: h(r) = (dk/dr)/r = -k(r), and k is the resident K_nm tile this workgroup's rows and
             // columns address -- no distances, no exp.  (k == var  <=>  r == 0, where T is 0 upstream.)
             double wvc[TN], csum[TN];
@@ -930,6 +933,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 #endif
             continue;
         }
+        if (TAG != 5) continue;
         // one feature chunk (the host fuses only when D <= DC): stage, then one row block
         // of accumulators at a time to keep the register footprint at acc + 16 doubles
         __syncthreads();
@@ -1094,6 +1098,7 @@ static void launch_variant(bool akm, bool bkm, int tag, dim3 grid, hipStream_t s
     if (tag == 9 && akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, true, 9>), grid, dim3(256), dyn_lds, s, g);
     else if (tag == 1 && akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, true, 1>), grid, dim3(256), dyn_lds, s, g);
     else if (tag == 2 && !akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, true, 2>), grid, dim3(256), dyn_lds, s, g);
+    else if (tag == 5 && !akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, true, 5>), grid, dim3(256), dyn_lds, s, g);
     else if (tag == 3 && !akm && !bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, false, 3>), grid, dim3(256), dyn_lds, s, g);
     else if (tag == 4 && !akm && !bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, false, 4>), grid, dim3(256), dyn_lds, s, g);
     else if (akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, true, 0>), grid, dim3(256), dyn_lds, s, g);
@@ -1212,9 +1217,10 @@ static int gemm_impl(Ctx* c, bool transA, bool transB, int M, int N, int K, doub
         if (stamp_count * 48 <= (64u << 20)) { HIP_TRY(hipMemsetAsync(stamp_dev, 0, stamp_count * 48, c->stream)); g.stamps = stamp_dev; }
     }
 #endif
+    const int etag = (o.tag == 2 && g.fuse_on && g.fuse.K == nullptr) ? 5 : o.tag;     // one fused epilogue per kernel
     if (narrow) hipLaunchKernelGGL((gemm_f64_kernel<64, 32, true, true, 0>), grid, dim3(256), 0, c->stream, g);
-    else if (tile == 128) launch_variant<128, 128>(akm, bkm, o.tag, grid, c->stream, g, (unsigned)o.dyn_lds);
-    else launch_variant<64, 64>(akm, bkm, o.tag, grid, c->stream, g, (unsigned)(o.dyn_lds ? o.dyn_lds : c->gemm_pad_now));
+    else if (tile == 128) launch_variant<128, 128>(akm, bkm, etag, grid, c->stream, g, (unsigned)o.dyn_lds);
+    else launch_variant<64, 64>(akm, bkm, etag, grid, c->stream, g, (unsigned)(o.dyn_lds ? o.dyn_lds : c->gemm_pad_now));
     HIP_TRY(hipGetLastError());
 #ifdef EDRGP_TILE_STAMPS
     if ((o.tag == 2 || stamp_phi) && g.stamps == stamp_dev && stamp_dev != nullptr) {       // every launch overwrites the file: the last one stays
