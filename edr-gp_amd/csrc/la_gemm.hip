@@ -46,6 +46,13 @@ constexpr int LPAD = 16;
 #ifndef EDRGP_FRAG_PIPE
 #define EDRGP_FRAG_PIPE 3
 #endif
+#ifndef EDRGP_EARLY_KK
+#define EDRGP_EARLY_KK 2         // k-step (of 4) after whose MFMAs the next tile's registers go to LDS
+#endif
+#ifndef EDRGP_PIPE_M2
+#define EDRGP_PIPE_M2 3         // gradient contraction: MFMAs between two fragment reads (6 read instructions per k-step;
+                                // Cm bound+gradients with 1 / 2 / 3 / 4: 23.15 / 23.15 / 22.86 / 22.92 ms)
+#endif
 #ifndef EDRGP_PIPE_M
 #define EDRGP_PIPE_M 4          // Phi: MFMAs between two fragment reads of the next k-step (1: 6.39, 2: 6.32, 3: 6.38, 4: 6.29 ms)
 #endif
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     // m-major operand images (row stride 18 doubles) are read with unmerged ds_read_b64 (frag_read): 128-wide tiles
     constexpr bool VOL_FRAG = (EDRGP_UNMERGED_MMAJOR_READS != 0) && BM == 128 && BN == 128;
     constexpr bool T25 = (TAG == 2 || TAG == 5);      // gradient contraction: 2 = RBF epilogue (k from the resident K_nm), 5 = distance-recomputing epilogue
-    constexpr int PIPE_M = (BM != 128) ? 1 : (T25 ? 2 : EDRGP_PIPE_M);   // the contraction has 6 read instructions per k-step, Phi 4
+    constexpr int PIPE_M = (BM != 128) ? 1 : (T25 ? EDRGP_PIPE_M2 : EDRGP_PIPE_M);   // the contraction has 6 read instructions per k-step, Phi 4
     constexpr bool FRAG_PIPE = (EDRGP_FRAG_PIPE != 0) && ((BM == 128 && BN == 128 && (TAG == 1 || TAG == 9 || (T25 && EDRGP_FRAG_PIPE >= 2))) ||
                                                            (EDRGP_FRAG_PIPE >= 3 && BM == 64 && BN == 64));
     typedef TileLoader<BM, AKM> LA;
@@ -733,7 +740,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                         }
                     }
                     __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);          // the rest of this step's MFMAs
-                    if (EARLY_STORE && kk == BK / 4 - 2) {
+                    if (EARLY_STORE && kk == EDRGP_EARLY_KK) {
                         __builtin_amdgcn_sched_barrier(0);
                         if (more) {
                             la.store(As[buf ^ 1], tid);
