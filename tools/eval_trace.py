@@ -7,7 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from edrgp_amd.backend import HipGP
 
-CFG = {"Cm": (100000, 2048, 32), "C2": (100000, 1024, 16), "C4": (200000, 1024, 64)}
+CFG = {"Cm": (100000, 2048, 32), "C2": (100000, 1024, 16), "C4": (200000, 1024, 64), "C3s": (125000, 2048, 32)}
+KIND = {"C3s": "Matern52"}
 name = sys.argv[1] if len(sys.argv) > 1 else "Cm"
 what = sys.argv[2] if len(sys.argv) > 2 else "grad"
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
@@ -18,7 +19,7 @@ for kv in sys.argv[4:]:
     k, v = kv.split("=")
     h.set_option(k, float(v))
 h.set_data(X, y); h.set_inducing(Z)
-h.set_kernel(["RBF"], [1.0], np.full((1, D), np.sqrt(D)), 0.01)
+h.set_kernel([KIND.get(name, "RBF")], [1.0], np.full((1, D), np.sqrt(D)), 0.01)
 f = h.sparse_lml_grad if what == "grad" else (h.sparse_posterior if what == "post" else h.sparse_lml)
 f(); f()
 h.sync()
