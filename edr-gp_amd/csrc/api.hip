@@ -376,6 +376,7 @@ int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
     else if (!std::strcmp(key, "kmm_early")) c->kmm_early = (int)value;
     else if (!std::strcmp(key, "side_gemm_pad")) c->side_gemm_pad = (int)value;
     else if (!std::strcmp(key, "skinny_split")) c->skinny_split = (int)value;
+    else if (!std::strcmp(key, "h_resident")) c->h_resident = (int)value;
     else if (!std::strcmp(key, "gemm_narrow")) c->gemm_narrow = (int)value;
     else if (!std::strcmp(key, "grad_finish_dev")) c->grad_finish_dev = (int)value;
     else if (!std::strcmp(key, "gemm_interleave")) c->gemm_interleave = (int)value;
@@ -815,7 +816,8 @@ int edrgp_dbg_gemm32(edrgp_ctx* ctx, int transA, int transB, int M, int N, int K
     TRY(dC.reserve((size_t)M * ldc * sizeof(float)));
     HIP_TRY(hipMemcpy(dA.p, A, ra * lda * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dB.p, B, rb * ldb * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(dC.p, 0, (size_t)M * ldc * sizeof(float)));
+    // on the context's stream: a null-stream memset is not ordered against this (non-blocking) stream's kernels
+    HIP_TRY(hipMemsetAsync(dC.p, 0, (size_t)M * ldc * sizeof(float), c->stream));
     int s = gemm32(c, transA != 0, transB != 0, M, N, K, static_cast<const float*>(dA.p), lda,
                    static_cast<const float*>(dB.p), ldb, static_cast<float*>(dC.p), ldc);
     if (s == EDRGP_OK && hipStreamSynchronize(c->stream) != hipSuccess) { set_error("dbg_gemm32: kernel failed"); s = EDRGP_ERR_HIP; }
@@ -865,7 +867,10 @@ int edrgp_dbg_potrf_inv(edrgp_ctx* ctx, double* A, int n, int* info, double* Lin
     TRY(dI.reserve((size_t)n * n * sizeof(double)));
     TRY(c->info.reserve(4 * sizeof(int)));
     HIP_TRY(hipMemcpy(dA.d(), A, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(dI.d(), 0xff, (size_t)n * n * sizeof(double)));          // NaN pattern: every entry must be written
+    // NaN pattern: every entry must be written.  On the context's stream: a null-stream memset is not ordered against
+    // this (non-blocking) stream's kernels and could land on top of entries the factorisation had already written (seen
+    // once as a failing test_potrf_with_inverse[3072] in a long test process)
+    HIP_TRY(hipMemsetAsync(dI.d(), 0xff, (size_t)n * n * sizeof(double), c->stream));
     TRY(potrf_inv_lower(c, dA.d(), n, n, static_cast<int*>(c->info.p), dI.d(), n));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(A, dA.d(), (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost));

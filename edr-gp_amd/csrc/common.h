@@ -80,7 +80,8 @@ struct FuseT {
     const double* invl;     // D
     double* dvpart;         // one partial per workgroup
     double* cspart;         // tiles_m x M partial column sums of T (or null)
-    const double* K;        // RBF only (or null): the resident K_nm chunk, h(r) = -k(r) needs no distances
+    const double* K;        // (or null) the resident K_nm chunk: RBF takes h(r) = -k(r) from it, no distances
+    const double* H = nullptr;  // (or null) h(r) = (dk/dr)/r of the same chunk, written by the build (other kernels), ld = ldk
     int ldk;
     double ycoef, var;
     int D, kind;
@@ -99,6 +100,8 @@ struct FuseK {
     double var, jitter;
     int kind, same;
     int dbg;                // diagnostic: 1 no exp, 2 no store
+    double* H = nullptr;    // (or null) h(r) = (dk/dr)/r stored beside K (0 where r = 0)
+    int ldh = 0;
 };
 
 struct GemmOpts {
@@ -252,6 +255,7 @@ struct Ctx {
     int gemm_interleave = 2;          // zero-skipping products: 1 tiles dealt round-robin to the XCDs, 2 also length-ranked snake over the CUs (la_gemm.hip)
     int grad_finish_dev = 1;          // finish dZ / d lengthscale on the device (sparse_eval.hip)
     int gemm_narrow = 1;              // 64 x 32 tiles for TN products with at most 32 columns (la_gemm.hip)
+    int h_resident = 1;               // non-RBF kernels: the build stores h(r) beside k, the contraction reads it (sparse_eval.hip)
     int skinny_split = 1;             // split-K for skinny outputs with 64 <= k-tiles < 256 (la_gemm.hip)
     int side_gemm_pad = 0;            // see gemm_pad_now
     int gemm_pad_now = 0;             // dynamic LDS padding of the 64 x 64 products queued beside a factorisation (bytes)
@@ -319,6 +323,7 @@ struct Ctx {
     DBuf mats[16];                    // M x M (or N x N dense) matrices
     DBuf ptw;                         // -diag(wv) [P | 1 | P.^2] of the RBF predict-gradient path
     bool knm_train_valid = false;     // c->Knm holds K(X, Z) of ALL training rows for the current theta / Z
+    DBuf Hnm;                         // h(r) of the resident K_nm chunk (non-RBF single-part kernels, gradient evaluations)
     DBuf gfin;                        // dZ (Mr x D) and per-block partial sums of the length-scale terms (grad_finish)
     DBuf g2;                          // T^T [X | X.^2] and column sums of T (fused gradient path)
     DBuf slabs, bpart, scal, info, gt_nm, gt_mm, tmpvec[6], panel, trtri_ws, dinv, red, lbaug;
@@ -327,6 +332,7 @@ struct Ctx {
     DBuf ep_K, ep_Sigma, ep_vec;      // EP classifier (ep_eval.hip): K, Sigma (N x N), site / cavity / moment vectors
     bool ep_begun = false, ep_valid = false;
     double ep_logZt = 0.0;            // log Z_tilde of the fitted sites
+    double* kbuild_h = nullptr;       // the next MFMA build also stores h(r) here (ld = its K's): set around build_knm
     bool kbuild_r2 = false;           // the MFMA build stores r^2 instead of k(r^2) (set around the sweep's distance pass)
     std::vector<double> host_scal;
     std::vector<double> Z_host;       // host copy of the inducing inputs (gradient finishing)

@@ -271,6 +271,7 @@ static int kernel_matrix_mfma(Ctx* c, const KSpec& ks, const double* X, int64_t 
     FuseK f;
     f.xn = c->ks_xn.d(); f.zn = zn; f.y = y; f.bpart = nullptr;
     f.var = ks.var[0]; f.jitter = jitter; f.kind = ks.kind[0]; f.same = same; f.dbg = c->kbuild_r2 ? 1 : (same ? 0 : c->kbuild_dbg);
+    f.H = c->kbuild_h; f.ldh = ldk;
     if (y != nullptr) {
         TRY(c->bpart.reserve((size_t)tiles_m * M2 * sizeof(double)));
         f.bpart = c->bpart.d();

@@ -412,7 +412,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     constexpr bool EARLY_STORE = (BM == 128);      // long MFMA phase: stage the next tile mid-phase
     // m-major operand images (row stride 18 doubles) are read with unmerged ds_read_b64 (frag_read): 128-wide tiles
     constexpr bool VOL_FRAG = (EDRGP_UNMERGED_MMAJOR_READS != 0) && BM == 128 && BN == 128;
-    constexpr bool T25 = (TAG == 2 || TAG == 5);      // gradient contraction: 2 = RBF epilogue (k from the resident K_nm), 5 = distance-recomputing epilogue
+    // gradient contraction: 2 = RBF epilogue (h = -k, k from the resident K_nm), 7 = k and h(r) both resident (Matern),
+    // 5 = distance-recomputing epilogue
+    constexpr bool T25 = (TAG == 2 || TAG == 5 || TAG == 7);
     constexpr int PIPE_M = (BM != 128) ? 1 : (T25 ? EDRGP_PIPE_M2 : EDRGP_PIPE_M);   // the contraction has 6 read instructions per k-step, Phi 4
     constexpr bool FRAG_PIPE = (EDRGP_FRAG_PIPE != 0) && ((BM == 128 && BN == 128 && (TAG == 1 || TAG == 9 || (T25 && EDRGP_FRAG_PIPE >= 2))) ||
                                                            (EDRGP_FRAG_PIPE >= 3 && BM == 64 && BN == 64));
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 #ifdef EDRGP_TILE_STAMPS
     // probe build (tools/tile_stamps.py): wall-clock stamps (100 MHz) of this workgroup's phases, contraction only
     unsigned long long ts_entry = 0, ts_loop = 0, ts_loop_end = 0;
-    if (TAG == 2 || TAG == 1) ts_entry = __builtin_amdgcn_s_memrealtime();
+    if (T25 || TAG == 1) ts_entry = __builtin_amdgcn_s_memrealtime();
 #endif
 
     // Two workgroups share a CU (two waves per SIMD).  Launched together and doing
@@ -526,7 +528,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 #else
     constexpr bool T1P = (TAG == 1);
 #endif
-    if ((TAG == 2 || TAG == 5 || TAG == 4 || T1P) && g.persist) {
+    if ((T25 || TAG == 4 || T1P) && g.persist) {
         const int total = g.persist;
         const int q = total >> 3, r = total & 7, x = (int)blockIdx.x & 7;
         p_in = (int)blockIdx.x >> 3;
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
             ti = tj = pair_d0;
         }
         if (pass) __syncthreads();                     // the previous unit is done with the LDS
-    } else if ((TAG == 2 || TAG == 5) && g.persist) {
+    } else if (T25 && g.persist) {
         t = p_start + pass * p_per + p_in;
         ti = t / g.tiles_n;
         tj = t - ti * g.tiles_n;
@@ -584,9 +586,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     // (249 -> 256 VGPRs + 164 B of scratch per lane).
     int tid_l = tid0;
 #ifdef EDRGP_NO_LAUNDER_T1
-    if (TAG == 2 || TAG == 5 || TAG == 4) asm volatile("" : "+v"(tid_l));
+    if (T25 || TAG == 4) asm volatile("" : "+v"(tid_l));
 #else
-    if (TAG == 1 || TAG == 2 || TAG == 5 || TAG == 4) asm volatile("" : "+v"(tid_l));
+    if (TAG == 1 || T25 || TAG == 4) asm volatile("" : "+v"(tid_l));
 #endif
     const int tid = tid_l;
     const int lane = tid & 63, wave = tid >> 6;
@@ -673,7 +675,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         lb.store(Bs[0], tid);
         __syncthreads();
 #ifdef EDRGP_TILE_STAMPS
-        if (TAG == 2) ts_loop = __builtin_amdgcn_s_memrealtime();
+        if (T25) ts_loop = __builtin_amdgcn_s_memrealtime();
 #endif
         // TAG 9 = diagnostic build of the Phi kernel: per-wave cycle sums of the loop
         // phases (load issue / MFMA / wait+LDS store / barrier), never used in production
@@ -791,7 +793,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         }
 #undef GEMM_STAMP
 #ifdef EDRGP_TILE_STAMPS
-        if (TAG == 2) ts_loop_end = __builtin_amdgcn_s_memrealtime();
+        if (T25) ts_loop_end = __builtin_amdgcn_s_memrealtime();
 #endif
         if (TAG == 9 && g.stamps != nullptr && lane == 0 && blockIdx.x == 5 && blockIdx.y == 2) {
             unsigned long long* o = g.stamps + wave * 4;
@@ -828,6 +830,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                     if (diag) Kv += f.jitter;
                     if (rok && col < g.N) {
                         if (!(f.dbg & 2) || Kv == 12345.678) C[(size_t)row * g.ldc + col] = Kv;
+                        // h(r) = (dk/dr) / r beside k for the gradient contraction of non-RBF kernels (0 where r = 0:
+                        // T is 0 there upstream)
+                        if (f.H != nullptr) f.H[(size_t)row * f.ldh + col] = (r2 == 0.0) ? 0.0 : hv;
                         bsum[y] = fma(Kv, yr, bsum[y]);
                     }
                 }
@@ -850,7 +855,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     }
 
     // ---- fused gradient epilogue (TAG 2): T = (acc + ycoef y wv^T) .* h(r), sum Q .* k / var
-    if ((TAG == 2 || TAG == 5) && g.fuse_on) {
+    if (T25 && g.fuse_on) {
         // scaled inputs of this tile's rows / columns, staged in the (now idle) operand LDS:
         // Xs[q][BM] = X[m0 + i][q] * invl[q], Zs[q][BN] = Z[n0 + j][q] * invl[q]
         constexpr int DC = 32;                               // feature chunk
@@ -858,8 +863,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         double* Xs = &As[0][0];
         double* Zs = &Bs[0][0];
         const FuseT& f = g.fuse;
-        if (TAG == 2) {
-            // (the host launches TAG 2 only with f.K set: one epilogue per kernel -- with both in one kernel the
+        if (TAG == 2 || TAG == 7) {
+            // (the host launches TAG 2 / 7 only with f.K (and f.H) set: one epilogue per kernel -- with both in one kernel the
             // contraction sat at 254-256 VGPRs and 221 spilled SGPRs, alone the RBF one takes 234 / 56)
             // RBF: h(r) = (dk/dr)/r = -k(r), and k is the resident K_nm tile this workgroup's rows and
             // columns address -- no distances, no exp.  (k == var  <=>  r == 0, where T is 0 upstream.)
@@ -884,6 +889,35 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                 const double* yb = f.y + m0 + wmu * WM;
                 const unsigned vk = (unsigned)((lq * f.ldk + lr) * 8), vc = (unsigned)((lq * g.ldc + lr) * 8);
                 const double nvar = f.var;
+                if (TAG == 7) {
+                    // k and h both from memory, loaded one row of the block at a time (8 values in flight per lane:
+                    // two 4 x 4 register blocks would not fit beside the accumulators)
+                    const char* Hb = reinterpret_cast<const char*>(f.H + (size_t)(m0 + wmu * WM) * f.ldk + n0 + wnu * WN);
+#pragma unroll
+                    for (int x = 0; x < TM; ++x) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const char* kr = Kb + (size_t)(x * 16 + 4 * r) * f.ldk * 8;
+                            const char* hr = Hb + (size_t)(x * 16 + 4 * r) * f.ldk * 8;
+                            char* cr = Cb + (size_t)(x * 16 + 4 * r) * g.ldc * 8;
+                            double kv[TN], hv[TN];
+#pragma unroll
+                            for (int y = 0; y < TN; ++y) {
+                                kv[y] = *reinterpret_cast<const double*>(kr + vk + y * 128);
+                                hv[y] = *reinterpret_cast<const double*>(hr + vk + y * 128);
+                            }
+                            const double ys = f.ycoef * yb[x * 16 + 4 * r + lq];
+#pragma unroll
+                            for (int y = 0; y < TN; ++y) {
+                                const double Q = fma(ys, wvc[y], acc[x][y][r]);
+                                dv = fma(Q, kv[y], dv);
+                                const double tval = Q * hv[y];
+                                *reinterpret_cast<double*>(cr + vc + y * 128) = tval;
+                                csum[y] += tval;
+                            }
+                        }
+                    }
+                } else
 #pragma unroll
                 for (int x = 0; x < TM; ++x) {
                     double kv[4][TN], yr[4];
@@ -922,7 +956,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                             const double Kv = f.K[(size_t)row * f.ldk + col];
                             const double Q = fma(yr, wvc[y], acc[x][y][r]);
                             dv = fma(Q, Kv, dv);
-                            const double tval = (Kv == f.var) ? 0.0 : -(Q * Kv);
+                            const double tval = (TAG == 7) ? Q * f.H[(size_t)row * f.ldk + col]
+                                                           : ((Kv == f.var) ? 0.0 : -(Q * Kv));
                             C[(size_t)row * g.ldc + col] = tval;
                             csum[y] += tval;
                         }
@@ -940,7 +975,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 #endif
             continue;
         }
-        if (TAG != 5) continue;
+        if (TAG != 5) continue;                            // 2 / 7 carry the memory-resident epilogue only
         // one feature chunk (the host fuses only when D <= DC): stage, then one row block
         // of accumulators at a time to keep the register footprint at acc + 16 doubles
         __syncthreads();
@@ -1009,6 +1044,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         }
         fused_epilogue_reduce<BN, WN, TN>(f, csum, dv, &Bs[0][0], tid, wm, wn, lr, lq, n0, g.N, ti,
                                           g.persist ? (size_t)t : (size_t)blockIdx.z * gridDim.x + blockIdx.x);
+#ifdef EDRGP_TILE_STAMPS
+        if (TAG == 5 && g.stamps != nullptr && tid == 0) {
+            unsigned long long* o = g.stamps + (size_t)(g.persist ? t : (int)blockIdx.x) * 6;
+            o[0] = ts_entry; o[1] = ts_loop; o[2] = ts_loop_end; o[3] = __builtin_amdgcn_s_memrealtime();
+            o[4] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+            o[5] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
+        }
+#endif
         continue;
     }
 
@@ -1106,6 +1149,7 @@ static void launch_variant(bool akm, bool bkm, int tag, dim3 grid, hipStream_t s
     else if (tag == 1 && akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, true, 1>), grid, dim3(256), dyn_lds, s, g);
     else if (tag == 2 && !akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, true, 2>), grid, dim3(256), dyn_lds, s, g);
     else if (tag == 5 && !akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, true, 5>), grid, dim3(256), dyn_lds, s, g);
+    else if (tag == 7 && !akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, true, 7>), grid, dim3(256), dyn_lds, s, g);
     else if (tag == 3 && !akm && !bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, false, 3>), grid, dim3(256), dyn_lds, s, g);
     else if (tag == 4 && !akm && !bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, false, false, 4>), grid, dim3(256), dyn_lds, s, g);
     else if (akm && bkm) hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, true, true, 0>), grid, dim3(256), dyn_lds, s, g);
@@ -1224,7 +1268,8 @@ static int gemm_impl(Ctx* c, bool transA, bool transB, int M, int N, int K, doub
         if (stamp_count * 48 <= (64u << 20)) { HIP_TRY(hipMemsetAsync(stamp_dev, 0, stamp_count * 48, c->stream)); g.stamps = stamp_dev; }
     }
 #endif
-    const int etag = (o.tag == 2 && g.fuse_on && g.fuse.K == nullptr) ? 5 : o.tag;     // one fused epilogue per kernel
+    // one fused epilogue per kernel: 2 = k from K_nm (RBF), 7 = k and h from memory, 5 = distances recomputed
+    const int etag = (o.tag == 2 && g.fuse_on) ? (g.fuse.K == nullptr ? 5 : (g.fuse.H != nullptr ? 7 : 2)) : o.tag;
     if (narrow) hipLaunchKernelGGL((gemm_f64_kernel<64, 32, true, true, 0>), grid, dim3(256), 0, c->stream, g);
     else if (tile == 128) launch_variant<128, 128>(akm, bkm, etag, grid, c->stream, g, (unsigned)o.dyn_lds);
     else launch_variant<64, 64>(akm, bkm, etag, grid, c->stream, g, (unsigned)(o.dyn_lds ? o.dyn_lds : c->gemm_pad_now));

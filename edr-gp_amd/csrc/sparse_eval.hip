@@ -114,6 +114,7 @@ struct SparseEval {
     bool kmmi_pending = false;    // ... and the main stream has not waited for it yet
     bool fin_dev = false;         // dZ / d lengthscale finished on the device (grad_finish)
     int fin_blocks = 0;
+    bool h_built = false;         // the K_nm chunk in c->Knm has its h(r) companion in c->Hnm
     bool tma_done = false;        // Lm^-T A Lm^-1 (Kmm term) was formed on the side stream beside the factorisation of B
     bool k32_resident = false;
     // precision 32 asks for the fp32 row pass; it is used while the Gram form is safe in fp32 (error ~ eps32
@@ -180,7 +181,7 @@ struct SparseEval {
         f32 = want32 && c->f32_phi && !c->phi32_bad;
         // the fused one-launch-per-step factorisation covers n in (64, 3072]; outside it the explicit inverse stays
         rhs_row = !need_grad && !need_post && c->chol_rhs && c->chol_fused && M > 64 && M + 1 <= 3072;
-        k_resident = prebuilt = kmmi_done = kmmi_pending = tma_done = k32_resident = false;
+        k_resident = prebuilt = kmmi_done = kmmi_pending = tma_done = k32_resident = h_built = false;
         return EDRGP_OK;
     }
 
@@ -225,8 +226,27 @@ struct SparseEval {
 
     // ------------------------------------------------------------------ phase 2
     // K(X[r0 : r0 + rows], Z) into `outK` (ld M) and, when yv is given, K^T yv into bt; phantom columns are zero
+    // Non-RBF single-part kernels in a gradient evaluation: the build stores h(r) = (dk/dr)/r beside k, and the gradient
+    // contraction reads both instead of recomputing distances, sqrt and exp per element in its epilogue -- fp64 VALU
+    // work crawls beside the partner workgroup's MFMA stream (Matern-5/2, D = 32: 108 us of epilogue per 470 us tile,
+    // tools/tile_stamps.py).  One more N x M array (1.6 GB at Cm, written once per evaluation).
+    bool want_h() const {
+        return need_grad && np == 1 && c->kind[0] != EDRGP_KERN_RBF && c->fuse_grad && c->h_resident && c->mfma_kbuild && !g32 &&
+               c->rbf_epilogue;
+    }
     int build_knm(int64_t r0, int64_t rows, double* outK, const double* yv, double* bt) {
-        TRY(kernel_matrix(c, ks, c->X.d() + (size_t)r0 * D, rows, c->Z.d(), Mr, outK, M, 0, 0.0, yv, bt));
+        const bool with_h = want_h() && outK == c->Knm.d();
+        if (with_h) {
+            TRY(c->Hnm.reserve((size_t)chunk * M * sizeof(double)));
+            c->kbuild_h = c->Hnm.d();
+        }
+        const int st = kernel_matrix(c, ks, c->X.d() + (size_t)r0 * D, rows, c->Z.d(), Mr, outK, M, 0, 0.0, yv, bt);
+        c->kbuild_h = nullptr;
+        if (st != EDRGP_OK) return st;
+        h_built = with_h;
+        if (padded && with_h)
+            HIP_TRY(hipMemset2DAsync(c->Hnm.d() + Mr, (size_t)M * sizeof(double), 0, (size_t)(M - Mr) * sizeof(double), (size_t)rows,
+                                     c->stream));
         if (padded) {
             HIP_TRY(hipMemset2DAsync(outK + Mr, (size_t)M * sizeof(double), 0, (size_t)(M - Mr) * sizeof(double), (size_t)rows,
                                      c->stream));
@@ -551,7 +571,7 @@ struct SparseEval {
             }
             // the distance-recomputing epilogue stages D <= 32 features; the RBF epilogue reads k from K_nm: any D
             const bool fused = (np == 1) && c->fuse_grad &&
-                               (D <= 32 || (c->kind[0] == EDRGP_KERN_RBF && c->rbf_epilogue));
+                               (D <= 32 || (c->kind[0] == EDRGP_KERN_RBF && c->rbf_epilogue) || h_built);
             if (fused) {
                 // T = (K_nm S2 + beta y wv^T) .* h(r) and the d/dvariance partials straight out of
                 // the contraction's epilogue: no W round trip, no separate element-wise pass
@@ -569,6 +589,10 @@ struct SparseEval {
                 f.cspart = c->bpart.d();
                 // RBF: the epilogue reads k from the resident K_nm chunk instead of recomputing distances
                 f.K = (c->kind[0] == EDRGP_KERN_RBF && c->rbf_epilogue) ? c->Knm.d() : nullptr;
+                if (h_built) {                        // k and h(r) both resident: any D, no distances in the epilogue
+                    f.K = c->Knm.d();
+                    f.H = c->Hnm.d();
+                }
                 f.ldk = M;
                 double* G2 = c->g2.d();
                 double* csv = G2 + (size_t)M * 2 * D;

@@ -10,7 +10,8 @@ N, M, D = 100000, 2048, 32
 X, y, Z = bench.synthetic(N, D, M, seed=bench.RANK0_SEED)
 h = HipGP(0)
 h.set_data(X, y); h.set_inducing(Z)
-h.set_kernel(["RBF"], [1.0], np.full((1, D), np.sqrt(D)), 0.01)
+KIND = os.environ.get("KIND", "RBF")
+h.set_kernel([KIND], [1.0], np.full((1, D), np.sqrt(D)), 0.01)
 for kv in sys.argv[1:]:
     k, v = kv.split("=")
     h.set_option(k, float(v))
