@@ -292,6 +292,7 @@ int ep_sites(Ctx* c, double* tau, double* v, const double* tau_in, const double*
         if (!c->have_data) { set_error("EP: set_data first"); return EDRGP_ERR_STATE; }
         const int n = (int)c->N;
         TRY(c->ep_vec.reserve((size_t)EP_NVEC * n * sizeof(double)));
+        HIP_TRY(hipStreamSynchronize(c->stream));          // nothing in flight may still read the old sites
         HIP_TRY(hipMemcpy(c->ep_vec.d() + (size_t)EP_TAU * n, tau_in, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->ep_vec.d() + (size_t)EP_V * n, v_in, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
         c->ep_logZt = logZt_in;
