@@ -100,7 +100,17 @@ int  edrgp_sync(edrgp_ctx* ctx);
  * "posterior_reuse" (edrgp_sparse_posterior right after a bound+gradient evaluation of the same state is
  *  served from that evaluation's factors),
  * "mfma_kbuild", "kbuild_tile" (64 / 128),
- * "gemm_dephase", "tri_tile";
+ * "gemm_dephase", "tri_tile",
+ * "gemm_persist" (0 off, 1 the gradient contraction, 2 also the stable form's product run as persistent grids of two
+ *  workgroups per CU), "syrk_persist" (the Phi launch likewise where it has the GPU to itself),
+ * "kmm_early" (Kmm-term products that need A only run beside the factorisation of I + A), "skinny_split",
+ * "gemm_interleave" (tile -> workgroup map of zero-skipping products: 0 XCD-contiguous, 1 round-robin, 2 length-ranked),
+ * "mid_split" (k-segments of lower-tiles-only products over triangular operands), "gemm_narrow" (64 x 32 tiles for
+ *  T^T X with at most 32 columns), "grad_finish_dev" (dZ / d lengthscale finished on the device),
+ * "h_resident" (non-RBF kernels: the K_nm build stores h(r) beside k for the gradient contraction; one more
+ *  N x M array), "kbuild_pad" / "side_gemm_pad" (LDS padding of launches that share the CUs with a factorisation);
+ * probes only (results are WRONG or unused): "gemm_alias", "dbg_gemm_kmode", "dbg_gemm_tri", "dbg_gemm_tile",
+ *  "dbg_gemm_reps" (tools/alias_probe.sh, tools/mid_gemm_probe.py);
  * "sync_free" (default 1): a sparse evaluation queues all its phases for the statistics form the previous one ended in
  *  and waits for the device once, at the end, where it also reads the device's verdict (Cholesky info words,
  *  pivot-ratio proxy); if the verdict disagrees -- jitter needed, or the other form -- the evaluation is repeated with
