@@ -1062,6 +1062,29 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         double bsum[TN];
 #pragma unroll
         for (int y = 0; y < TN; ++y) bsum[y] = 0.0;
+        if ((m0 + BM <= Meff) && (n0 + BN <= g.N) && ((long long)BM * g.ldc < (1LL << 28))) {
+            // interior tiles: wave-uniform row base + one per-lane byte offset, a store and an fma per element (every
+            // VALU instruction of an epilogue is paid beside the partner workgroup's MFMA stream: 15.6 us per pass with
+            // the guarded form below)
+            const int wu = __builtin_amdgcn_readfirstlane(wave);
+            const int wmu = wu >> 1, wnu = wu & 1;
+            char* Cb = reinterpret_cast<char*>(C + (size_t)(m0 + wmu * WM) * g.ldc + n0 + wnu * WN);
+            const double* yb = f.y + m0 + wmu * WM;
+            const unsigned vc = (unsigned)((lq * g.ldc + lr) * 8);
+#pragma unroll
+            for (int x = 0; x < TM; ++x)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    char* cr = Cb + (size_t)(x * 16 + 4 * r) * g.ldc * 8;
+                    const double yr = yb[x * 16 + 4 * r + lq];
+#pragma unroll
+                    for (int y = 0; y < TN; ++y) {
+                        const double v = acc[x][y][r];
+                        *reinterpret_cast<double*>(cr + vc + y * 128) = v;
+                        bsum[y] = fma(v, yr, bsum[y]);
+                    }
+                }
+        } else
 #pragma unroll
         for (int x = 0; x < TM; ++x)
 #pragma unroll

@@ -81,5 +81,8 @@ def run(h, seed=0, n_cases=60, modes=(0, 0, 1, 2), verbose=True, large=False):
 if __name__ == "__main__":
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-    failing = run(HipGP(0), seed, n, large=len(sys.argv) > 3 and sys.argv[3] == "large")
+    large = len(sys.argv) > 3 and sys.argv[3] == "large"
+    # forced Gram form (mode 1) is left out of the large shapes: their Kmm reaches cond 1e5 .. 1e11, where that form
+    # loses the digits the automatic rule avoids by switching
+    failing = run(HipGP(0), seed, n, modes=(0, 0, 2) if large else (0, 0, 1, 2), large=large)
     print("fuzz: %d cases, %d outside tolerance" % (n, len(failing)))
