@@ -759,7 +759,13 @@ struct SparseEval {
     int stage_phase1(bool careful, bool assume_stable, bool* rows_done) {
         *rows_done = false;
         const bool can_prebuild = c->overlap && nchunks == 1 && !f32 && c->prebuild;
-        const bool beside_rows = ((c->overlap == 2) || (c->overlap == 3 && !need_grad && !can_prebuild)) && !assume_stable;
+        // `can_prebuild` looks at the LOCAL chunk count, and a row pass queued here all-reduces Phi before the verdict
+        // on the form is known (a second all-reduce follows when the rule then asks for the stable form): with a
+        // communicator the choice must not depend on it, or a chunked rank would issue two collectives where a
+        // single-chunk rank issues one.  Sharded contexts therefore never take the local-count branch;
+        // `overlap` = 2 is an option every rank shares.
+        const bool beside_rows = ((c->overlap == 2) || (c->overlap == 3 && !need_grad && !can_prebuild && !c->sharded())) &&
+                                 !assume_stable;
         // Z and the hyper-parameters reach the device by asynchronous copies on the main stream
         // (edrgp_set_inducing / edrgp_set_kernel do not wait): the side stream starts behind them
         HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
@@ -913,7 +919,12 @@ struct SparseEval {
         // the verdict
         if (h_info[0] != 0 || h_info[1] != 0) { c->have_post = false; return RETRY_JITTER; }
         c->last_pivot_ratio2 = pivot_ratio2();
-        if (rule_says_stable() != stable) { c->have_post = false; return RETRY_CAREFUL; }
+        if (rule_says_stable() != stable) {
+            // the careful repeat starts from the form the rule has just asked for (no wasted row pass in the other one)
+            c->last_mode = rule_says_stable() ? 2 : 1;
+            c->have_post = false;
+            return RETRY_CAREFUL;
+        }
         c->last_mode = stable ? 2 : 1;
         set_bound();
         if (need_grad) {

@@ -41,18 +41,19 @@ def run_and_check(tmp_path, world, transport):
             assert min(sizes) <= chunk < max(sizes)
         # same form on every rank and on the whole problem (the rule looks at the replicated Kmm)
         assert len({float(r["mode"]) for r in ranks} | {float(whole["mode"])}) == 1, name
-        assert float(whole["mode"]) == (2.0 if (name.startswith("illcond") or name == "stable_forced") else 1.0), name
+        assert float(whole["mode"]) == (2.0 if ("illcond" in name or name == "stable_forced") else 1.0), name
         # replicated results: identical bits on every rank
         for k in range(1, world):
             for key in ("lml", "bound_only", "bound_post", "dvar", "dlen", "dnoise", "dZ", "mean", "var", "wv"):
                 assert np.array_equal(ranks[0][key], ranks[k][key]), (name, key, k)
         if "collectives" in ranks[0].files:          # every rank issued the same sequence of all-reduces
             for k in range(1, world):
-                assert np.array_equal(ranks[0]["collectives"], ranks[k]["collectives"]), (name, k)
+                assert np.array_equal(ranks[0]["collectives"], ranks[k]["collectives"]), \
+                    (name, k, ranks[0]["collectives"], ranks[k]["collectives"])
             Mw = (M + 127) // 128 * 128 if (M > 256 and M % 128) else M
             assert Mw * (Mw + 1) // 2 + Mw in set(int(v) for v in ranks[0]["collectives"])   # the packed triangle travelled
         # sharded == whole (different summation order of Phi only)
-        cond_slack = 100.0 if name.startswith("illcond") else 1.0
+        cond_slack = 100.0 if "illcond" in name else 1.0
         r0 = ranks[0]
         assert abs(r0["lml"] - whole["lml"]) <= 1e-10 * cond_slack * abs(whole["lml"]), name
         assert abs(r0["bound_only"] - whole["lml"]) <= 1e-10 * cond_slack * abs(whole["lml"])

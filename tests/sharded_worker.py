@@ -20,7 +20,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 # name, N, M, D, kind, lengthscale factor (x sqrt(D)), noise, chunk_rows, stats_mode, sync_free
+# A name that starts with "fresh_" runs on a NEW context (and communicator): no evaluation has told it which form
+# the previous Kmm took, so its first call -- a bound-only evaluation -- starts out assuming the Gram form on an
+# ill-conditioned Kmm.  With shards straddling chunk_rows that is the state in which a chunked rank used to queue
+# its row pass (one all-reduce) beside phase 1 and repeat it in the stable form (a second one) while the
+# single-chunk rank all-reduced once.
 CASES = [
+    ("fresh_illcond_auto",    2301, 96, 3, "RBF", 0.45, 0.01, 1024, 0, 1),
+    ("fresh_illcond_careful", 2301, 96, 3, "RBF", 0.45, 0.01, 1024, 0, 0),
     ("gram_auto",      2301, 96, 5, "RBF",      0.5, 0.05, 1024, 0, 1),
     ("gram_careful",   2301, 96, 5, "RBF",      0.5, 0.05, 1024, 0, 0),
     ("stable_forced",  1777, 64, 4, "Matern52", 1.0, 0.05, 1024, 2, 1),
@@ -76,21 +83,29 @@ def main():
     dist.init_process_group("gloo")                     # control plane (and, with --transport gloo, the data plane)
     from edrgp_amd.backend import HipGP
     dev = local_rank if args.transport == "rccl" else 0
-    h = HipGP(dev)
-    if args.transport == "rccl":
-        box = [HipGP.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        h.comm_init(world, rank, box[0])
-    else:
-        calls = []
+    calls = []
 
-        def allreduce(a):
-            calls.append(a.size)
-            dist.all_reduce(torch.from_numpy(a), op=dist.ReduceOp.SUM)
-        h.comm_init_host(world, rank, allreduce)
+    def allreduce(a):
+        calls.append(a.size)
+        dist.all_reduce(torch.from_numpy(a), op=dist.ReduceOp.SUM)
+
+    def sharded_context():
+        ctx = HipGP(dev)
+        if args.transport == "rccl":
+            box = [HipGP.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ctx.comm_init(world, rank, box[0])
+        else:
+            ctx.comm_init_host(world, rank, allreduce)
+        return ctx
+
+    h = sharded_context()
     whole = HipGP(dev) if rank == 0 else None
     try:
         for ci, (name, N, M, D, kind, lsf, noise, chunk, smode, sfree) in enumerate(CASES):
+            if name.startswith("fresh_") and ci > 0:
+                h.close()
+                h = sharded_context()
             X, y, Z = problem(N, D, M, seed=100 + ci)
             Xs = X[:64].copy()
             cuts = shard_bounds(N, world)

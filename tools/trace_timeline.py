@@ -8,8 +8,8 @@ ks = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name
 def short(n):
     n = re.sub(r"^void ", "", n); n = n.replace("edrgp::", "")
     return n[:70]
-# the last evaluation starts at the last pair_kernel / scale_norm launch that follows a gap > 200 us
-starts = [i for i in range(1, len(ks)) if ks[i][0] - max(k[1] for k in ks[max(0, i - 50):i]) > 150000]
+# the last evaluation starts behind the last idle gap > 2 ms (tools/eval_trace.py sleeps in front of it)
+starts = [i for i in range(1, len(ks)) if ks[i][0] - max(k[1] for k in ks[max(0, i - 50):i]) > 2000000]
 i0 = starts[-1] if starts else 0
 ev = ks[i0:]
 t0 = ev[0][0]
