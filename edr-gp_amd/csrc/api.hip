@@ -881,23 +881,6 @@ int edrgp_dbg_potrf_inv(edrgp_ctx* ctx, double* A, int n, int* info, double* Lin
     return EDRGP_OK;
 }
 
-// diagnostic: phase stamps (shader cycles) of one diagonal-block kernel launch
-int edrgp_dbg_diag_stamps(edrgp_ctx* ctx, const double* A64x64, int do_chol, double* stamps6) {
-    CTX(ctx);
-    DBuf dA, dD, dS;
-    TRY(dA.reserve(64 * 64 * sizeof(double)));
-    TRY(dD.reserve(64 * 64 * sizeof(double)));
-    TRY(dS.reserve(8 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemcpy(dA.d(), A64x64, 64 * 64 * sizeof(double), hipMemcpyHostToDevice));
-    int s = diag_block_stamps(c, dA.d(), dD.d(), static_cast<unsigned long long*>(dS.p), do_chol);
-    if (s == EDRGP_OK && hipStreamSynchronize(c->stream) != hipSuccess) s = EDRGP_ERR_HIP;
-    unsigned long long h[8] = {0};
-    if (s == EDRGP_OK) HIP_TRY(hipMemcpy(h, dS.p, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    for (int i = 0; i < 6; ++i) stamps6[i] = (double)(h[i] - h[0]);
-    dA.release(); dD.release(); dS.release();
-    return s;
-}
-
 int edrgp_dbg_trtri(edrgp_ctx* ctx, const double* L, double* Linv, int n) {
     CTX(ctx);
     DBuf dL, dI;

@@ -153,7 +153,6 @@ int trtri_lower(Ctx* c, const double* L, int ldl, double* Linv, int ldi, int n);
 int potrf_inv_lower(Ctx* c, double* A, int n, int lda, int* info_dev, double* Linv, int ldi);
 int potrf_inv_lower_batched(Ctx* c, double* A, int n, int lda, long long strideA, int* info_dev, double* Linv, int ldi,
                             long long strideI, int batch);
-int diag_block_stamps(Ctx* c, double* A64, double* Dinv64, unsigned long long* stamps_dev, int do_chol);
 
 // -------------------------------------------------------------- vector helpers
 int gemv_n(Ctx* c, int M, int N, double alpha, const double* A, int lda, const double* x, double* y);
@@ -245,7 +244,7 @@ struct Ctx {
     int M_work = 0;                   // working size of the last sparse evaluation (>= M)
     bool chol_rhs = true;             // bound-only evaluations: L_B^-1 (beta v) as an extra row of the factorisation, no explicit L_B^-1
     bool chol_fused = true;           // Cholesky: panel + trailing update in one launch per step (la_chol.hip)
-    bool chol_cap_grid = true;        // a step launch never has more workgroups than CUs (la_chol.hip)
+    bool chol_cap_grid = false;       // a step launch never has more workgroups than CUs (la_chol.hip); off since round 3: the bulk tiles, not workgroup 0, bound the wide steps
     bool chol_shares_gpu = false;     // set while a factorisation runs beside another kernel (phase 1 beside the K_nm build)
     bool chol_inv_fused = true;       // ... and the inverse of the factor out of the same launches
     bool rbf_epilogue = true;         // RBF: fused gradient epilogue takes h(r) = -k(r) from the resident K_nm

@@ -22,245 +22,23 @@
 // the next product (C/D reg r holds row (lane>>4)+4r = k of k-step r), so the X
 // tiles never leave registers; only A fragments (blocks of L and T) come from LDS.
 #include "common.h"
+#include "chol_diag.h"      // NB, d4, DIAG_LDS, diag_block_body: one 64 x 64 diagonal block on one workgroup
 
 namespace edrgp {
 
-constexpr int NB = 64;
-typedef double d4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readlane(lo, lane);
-    hi = __builtin_amdgcn_readlane(hi, lane);
-    return __hiloint2double(hi, lo);
-}
-
-// DO_CHOL: factor the block in place (jb <= 64 valid rows/cols, identity padding)
-// and report the first non-positive pivot; then (both modes) invert it.  Outputs:
-// the inverse into Dinv (dense 64x64, ld 64, blockIdx-th slab; upper blocks are
-// never written and must be zero) and/or into inv_out (ld ldi, jb x jb part).
-// LDS footprint of the body, in doubles: Lt[64][65] | Tl[4][16][17] = Pn[64][17] (the panel image is dead when the
-// inverse starts) | rdiag[64]: 42.5 KB, so that a workgroup carrying it fits into the LDS one retiring workgroup of
-// the K_nm build leaves free on a CU (160 KB - 3 x 36.9 KB) -- see chol_step_kernel
-constexpr int DIAG_LDS = NB * (NB + 1) + 4 * 16 * 17 + NB;
-
-// The body is a device function so that the fused Cholesky step kernel can run it on the workgroup that has
-// just finished the next diagonal tile (256 threads, `lds` = DIAG_LDS doubles, uniform call per workgroup).
-template <bool DO_CHOL, bool PRELOADED = false>
-__device__ __forceinline__ void diag_block_body(double* __restrict__ Abase, int lda, int n, int blk,
-                                                double* __restrict__ Dinv_slab, double* __restrict__ inv_out, int ldi,
-                                                int* __restrict__ info, unsigned long long* __restrict__ stamps,
-                                                double* __restrict__ Lbase, int ldlo, int info_off,
-                                                double* __restrict__ lds) {
-    double (*Lt)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(lds);                       // Lt[k][i] = L[i][k]
-    double (*Tl)[16][17] = reinterpret_cast<double (*)[16][17]>(lds + NB * (NB + 1));       // inverses of the 16x16 diagonal blocks
-    double* rdiag = lds + NB * (NB + 1) + 4 * 16 * 17;                                      // 1 / L[i][i]
-    double (*Pn)[17] = reinterpret_cast<double (*)[17]>(lds + NB * (NB + 1));               // current 16-column panel (aliases Tl)
-#define EDRGP_STAMP(slot) do { if (stamps != nullptr && threadIdx.x == 0) stamps[slot] = __builtin_amdgcn_s_memtime(); } while (0)
-    EDRGP_STAMP(0);
-    // 4 waves: all of them move data (load, write-back, the four column chains of the inverse); the
-    // serial factorisation runs on wave 0 alone, ordered through LDS without barriers (one wave's LDS
-    // instructions execute in order).
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j0 = blk * NB;
-    const int jb = min(NB, n - j0);
-    double* A = Abase + (size_t)j0 * lda + j0;
-    if (!PRELOADED) {                               // PRELOADED: the caller has filled Lt (identity padded) and synchronised
-        const int cl = min(lane, jb - 1);
-        const int r0 = 16 * wave;                   // coalesced, clamped (branch-free), 16 rows in flight per wave
-        double t[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) t[u] = A[(size_t)min(r0 + u, jb - 1) * lda + cl];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int r = r0 + u;
-            const bool in = (r < jb) && (lane < jb) && (lane <= r);
-            Lt[lane][r] = in ? t[u] : ((r == lane) ? 1.0 : 0.0);
-        }
-        __syncthreads();
-    }
-    EDRGP_STAMP(1);
-
-    if (DO_CHOL) {
-        if (wave == 0) {
-            // Blocked right-looking factorisation on one wave.  The trailing matrix lives in MFMA C/D tiles
-            // (10 lower 16x16 tiles, reg r of lane l = row (l>>4)+4r, col l&15); only the current 16-column
-            // panel is brought into "row per lane" registers for the 16 serial pivots, and its rank-16 update of
-            // the remaining tiles is 4 MFMAs per tile with both fragments read straight from the [k][row] image
-            // of L in LDS.  (The unblocked form spent ~500 cycles per pivot in LDS broadcast reads of the whole
-            // remaining row; here a pivot touches at most 15 values.)
-            const int lr = lane & 15, lq = lane >> 4;
-            d4 T[4][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int i = j; i < 4; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) T[i][j][r] = Lt[16 * j + lr][16 * i + lq + 4 * r];
-            int bad = 0;
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                // (1) panel s4 (tiles (i, s4), i >= s4) -> one row per lane
-#pragma unroll
-                for (int i = s4; i < 4; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) Pn[16 * i + lq + 4 * r][lr] = T[i][s4][r];
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                double p[16];
-#pragma unroll
-                for (int cidx = 0; cidx < 16; ++cidx) p[cidx] = (lane >= 16 * s4) ? Pn[lane][cidx] : 0.0;
-                // (2) the 16 pivots of the panel
-#pragma unroll
-                for (int jj = 0; jj < 16; ++jj) {
-                    const int j = 16 * s4 + jj;
-                    const double pv = readlane_f64(p[jj], j);
-                    if (!(pv > 0.0) && bad == 0) bad = info_off + j0 + j + 1;
-                    // 1/sqrt(pv): v_rsq_f64 + two Newton steps  y <- y (1.5 - 0.5 pv y^2)
-                    const double hp = 0.5 * pv;
-                    double y = __builtin_amdgcn_rsq(pv);
-                    y = y * fma(-hp, y * y, 1.5);
-                    y = y * fma(-hp, y * y, 1.5);
-                    double l = p[jj] * y;               // lane j: pv / sqrt(pv) = sqrt(pv)
-                    if (lane < j) l = 0.0;
-                    p[jj] = l;
-                    if (jj + 1 < 16) {
-                        // critical path first: the next pivot needs only l[j+1] (one readlane)
-                        const double cn = readlane_f64(l, j + 1);
-                        p[jj + 1] = fma(-l, cn, p[jj + 1]);
-                    }
-                    Lt[j][lane] = l;
-                    if (lane == j) rdiag[j] = y;
-                    // same-wave LDS write -> read: in order, no s_barrier; the fence keeps the compiler from
-                    // hoisting later reads above the store
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int kk = jj + 2; kk < 16; ++kk) p[kk] = fma(-l, Lt[j][16 * s4 + kk], p[kk]);
-                }
-                // (3) rank-16 update of the remaining tiles: T_ib -= P_i P_b^T
-                if (s4 < 3) {
-#pragma unroll
-                    for (int st = 0; st < 4; ++st) {
-                        double af[4], bf[4];
-#pragma unroll
-                        for (int i = s4 + 1; i < 4; ++i) {
-                            bf[i] = Lt[16 * s4 + 4 * st + lq][16 * i + lr];
-                            af[i] = -bf[i];
-                        }
-#pragma unroll
-                        for (int b = s4 + 1; b < 4; ++b)
-#pragma unroll
-                            for (int i = b; i < 4; ++i)
-                                T[i][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[b], T[i][b], 0, 0, 0);
-                    }
-                }
-            }
-            if (bad && lane == 0 && info != nullptr) atomicCAS(info, 0, bad);
-        }
-        __syncthreads();
-        EDRGP_STAMP(2);
-        // the factor goes back in place, or (out-of-place potrf) to the same block of Lbase
-        double* Lw = (Lbase != nullptr) ? Lbase + (size_t)j0 * ldlo + j0 : A;
-        const int ldw = (Lbase != nullptr) ? ldlo : lda;
-        {
-            const int r0 = 16 * wave;               // coalesced write-back, explicit zeros above the diagonal
-            double t[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) t[u] = Lt[lane][r0 + u];          // 16 LDS reads in flight
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int r = r0 + u;
-                if (r < jb && lane < jb) Lw[(size_t)r * ldw + lane] = (lane <= r) ? t[u] : 0.0;
-            }
-        }
-    } else {
-        if (wave == 0) rdiag[lane] = 1.0 / Lt[lane][lane];
-        __syncthreads();
-        EDRGP_STAMP(2);
-    }
-    EDRGP_STAMP(3);
-
-    // ---- inverse, step 1 (wave 0): T_b = inv(L_bb) for the four 16x16 diagonal blocks
-    if (wave == 0) {
-        const int b = lane >> 4, cidx = lane & 15, o = 16 * b;
-        double t[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) t[i] = (i == cidx) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            t[k] *= rdiag[o + k];
-            const double tk = t[k];
-#pragma unroll
-            for (int i = k + 1; i < 16; ++i) t[i] = fma(-Lt[o + k][o + i], tk, t[i]);    // L_bb[i][k]
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) Tl[b][i][cidx] = t[i];
-    }
-    __syncthreads();
-
-    // ---- inverse, step 2: block substitution on the matrix pipe; wave w owns block column j = w
-    // (X_jj, then X_ij for i > j, each a chain through the tiles above it in the same column)
-    const int lr = lane & 15, lq = lane >> 4;
-    const int j = wave;
-    d4 X[4];                                      // X[i] = X_ij, i >= j, C/D layout: reg r = row lq + 4r, col lr
-#pragma unroll
-    for (int i = 0; i < 4; ++i) X[i] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
-        if (jj == j) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) X[jj][r] = Tl[jj][lq + 4 * r][lr];
-        }
-#pragma unroll
-    for (int i = 1; i < 4; ++i) {
-        if (i > j) {
-            d4 S = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int k = 0; k < i; ++k) {
-                if (k >= j) {
-#pragma unroll
-                    for (int st = 0; st < 4; ++st) {
-                        // A fragment of L_ik: lane holds L[16i + lr][16k + 4 st + lq]
-                        const double af = Lt[16 * k + 4 * st + lq][16 * i + lr];
-                        S = __builtin_amdgcn_mfma_f64_16x16x4f64(af, X[k][st], S, 0, 0, 0);
-                    }
-                }
-            }
-            d4 Y = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                const double tf = -Tl[i][lr][4 * st + lq];          // A fragment of -T_ii
-                Y = __builtin_amdgcn_mfma_f64_16x16x4f64(tf, S[st], Y, 0, 0, 0);
-            }
-            X[i] = Y;
-        }
-    }
-    EDRGP_STAMP(4);
-    if (Dinv_slab) {
-        double* D = Dinv_slab;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (i >= j) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) D[(16 * i + lq + 4 * r) * NB + 16 * j + lr] = X[i][r];
-            }
-    }
-    if (inv_out) {
-        double* O = inv_out + (size_t)j0 * ldi + j0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (i >= j) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * i + lq + 4 * r, col = 16 * j + lr;
-                    if (row < jb && col < jb) O[(size_t)row * ldi + col] = X[i][r];
-                }
-            }
-    }
-    EDRGP_STAMP(5);
-#undef EDRGP_STAMP
-}
+#ifdef EDRGP_TILE_STAMPS
+// probe build (tools/chol_stamps.py): phases of workgroup 0 of every step launch -- the critical path of the
+// factorisation -- on the 100 MHz wall clock (slots 0..7) and, inside the diagonal-block body, in shader cycles
+// (slots 8..15, see chol_diag.h); 16 slots per step
+__device__ unsigned long long* g_chol_stamps = nullptr;
+#define CHOL_STAMP(slot)                                                                                        \
+    do {                                                                                                        \
+        if (g_chol_stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)                 \
+            g_chol_stamps[(size_t)k * 16 + (slot)] = __builtin_amdgcn_s_memrealtime();                         \
+    } while (0)
+#else
+#define CHOL_STAMP(slot) do { } while (0)
+#endif
 
 // Strides of a batch of independent matrices (blockIdx.y of the factorisation kernels); all zero = one matrix.
 struct CholBatch {
@@ -282,19 +60,6 @@ __global__ __launch_bounds__(256) void diag_block_kernel(double* __restrict__ Ab
                              Dinv ? Dinv + z * bt.sD + (size_t)blockIdx.x * NB * NB : nullptr,
                              inv_out ? inv_out + z * bt.sI : nullptr, ldi, info ? info + z * bt.sInfo : nullptr, stamps,
                              Lbase ? Lbase + z * bt.sL : nullptr, ldlo, info_off, lds);
-}
-
-// one factor+invert of a 64x64 block with phase stamps: diagnostic only
-int diag_block_stamps(Ctx* c, double* A64, double* Dinv64, unsigned long long* stamps_dev, int do_chol) {
-    HIP_TRY(hipMemsetAsync(Dinv64, 0, NB * NB * sizeof(double), c->stream));
-    if (do_chol)
-        hipLaunchKernelGGL(diag_block_kernel<true>, dim3(1), dim3(256), 0, c->stream, A64, 64, 64, 0, Dinv64,
-                           (double*)nullptr, 0, (int*)nullptr, stamps_dev);
-    else
-        hipLaunchKernelGGL(diag_block_kernel<false>, dim3(1), dim3(256), 0, c->stream, A64, 64, 64, 0, Dinv64,
-                           (double*)nullptr, 0, (int*)nullptr, stamps_dev);
-    HIP_TRY(hipGetLastError());
-    return EDRGP_OK;
 }
 
 __global__ void copy2d_kernel(const double* __restrict__ src, int lds, double* __restrict__ dst, int ldd,
@@ -341,6 +106,8 @@ __global__ void fill_kernel(double* __restrict__ A, size_t count, double v) {
 // steps of the Kmm factorisation (high-priority side stream) get workgroup slots while the build streams beside them;
 // with two tile images (67.6 KB) a step waited for two build workgroups of one CU to retire together, and the first
 // two steps of phase 1 took 494 + 164 us instead of 2 x 38.
+// (Every barrier of the kernel orders LDS traffic only -- lds_barrier() -- so that none of them waits for the global
+// stores of L_ik / the updated tile that are still in flight: __syncthreads() drains them, ~1 us each time.)
 template <bool CAPPED>
 __global__ __launch_bounds__(256, CAPPED ? 1 : 2) void chol_step_kernel(double* __restrict__ A, int lda, double* __restrict__ Lout,
                                                            int ldl, const double* __restrict__ Dinv, int n, int k,
@@ -370,6 +137,7 @@ __global__ __launch_bounds__(256, CAPPED ? 1 : 2) void chol_step_kernel(double* 
     // inverse of the next diagonal block -- had to share its CU.  The surplus tiles are walked by the workgroups
     // other than 0 (each ~6 us against workgroup 0's ~25).
     const int G = (int)gridDim.x;
+    CHOL_STAMP(0);
     d4 Cij[2][2];                        // the tile being updated (workgroup 0 keeps it for the diagonal-block body)
     bool next_diag = false;
     for (int tile = (int)blockIdx.x; tile < ntiles;) {
@@ -397,51 +165,100 @@ __global__ __launch_bounds__(256, CAPPED ? 1 : 2) void chol_step_kernel(double* 
     double* Ct = inv_tile ? Cw : A;
     const int ldp = inv_tile ? ldc : lda;
 
-    // Dinv fragments: b[st][y] = B[q = 4 st + lq][c = 32 wn + 16 y + lr] = Dinv[c][q]
-    double db[16][2];
-#pragma unroll
-    for (int st = 0; st < 16; ++st)
-#pragma unroll
-        for (int y = 0; y < 2; ++y) db[st][y] = Dinv[(32 * wn + 16 * y + lr) * NB + 4 * st + lq];
-
-    // every global operand is requested up front: the tile being updated (used in the epilogue) and both panel
-    // tiles (thread -> rows tid/32 + 8 v, columns 2 (tid % 32), 16-byte loads); the second one waits in registers
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = i0 + 32 * wm + 16 * x + lq + 4 * r, col = j0 + 32 * wn + 16 * y + lr;
-                Cij[x][y][r] = (!panel_only && !ident && row < n && col < n) ? Ct[(size_t)row * ldp + col] : 0.0;
-            }
+    // Dinv fragments (loaded below): b[st][y] = B[q = 4 st + lq][c = 32 wn + 16 y + lr] = Dinv[c][q]
+    // Every global operand is requested up front -- the Dinv fragments, the tile being updated (used in the epilogue)
+    // and both panel tiles (thread -> rows tid/32 + 8 v, columns 2 (tid % 32), 16-byte loads; the second one waits in
+    // registers).  The common case -- whole 64 x 64 tiles, aligned rows -- is ONE basic block of unconditional loads:
+    // operands a tile does not use (the identity block row of C, the second panel tile of a diagonal tile) are loaded
+    // from their (valid) addresses anyway and replaced afterwards.  (The guarded form had branches between the load
+    // groups and an LDS store per row group; the compiler waited for each group in turn -- up to ten memory latencies,
+    // 6.8 us of a 26 us step on the critical path: tools/chol_stamps.py.)
     const int c2 = (tid & 31) * 2, r8 = tid >> 5;
-    double2 a2v[8];
+    double db[16][2];
+    double2 a1v[8], a2v[8];
     {
         const bool al = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((lda & 1) == 0);
         const bool alp = ((reinterpret_cast<uintptr_t>(Pi) & 15) == 0) && ((ldp & 1) == 0);
+        const bool common = al && alp && !panel_only && (i0 + NB <= n) && (j0 + NB <= n);         // uniform
+        if (common) {
 #pragma unroll
-        for (int v = 0; v < 8; ++v) {
-            const int r = r8 + 8 * v;
-            double2 a1 = {0.0, 0.0};
-            a2v[v] = double2{0.0, 0.0};
-            if (ident) {
-                a1.x = (r == c2) ? 1.0 : 0.0;
-                a1.y = (r == c2 + 1) ? 1.0 : 0.0;
-            } else if (i0 + r < n) {
-                // (the panel columns are whole except in the panel-only launch, whose block column may be ragged)
-                const double* p = Pi + (size_t)(i0 + r) * ldp + k0 + c2;
-                if (alp && k0 + c2 + 1 < n) a1 = *reinterpret_cast<const double2*>(p);
-                else { a1.x = (k0 + c2 < n) ? p[0] : 0.0; a1.y = (k0 + c2 + 1 < n) ? p[1] : 0.0; }
+            for (int v = 0; v < 8; ++v) {
+                a1v[v] = *reinterpret_cast<const double2*>(Pi + (size_t)(i0 + r8 + 8 * v) * ldp + k0 + c2);
+                a2v[v] = *reinterpret_cast<const double2*>(A + (size_t)(j0 + r8 + 8 * v) * lda + k0 + c2);
             }
-            if (two && j0 + r < n) {
-                const double* p = A + (size_t)(j0 + r) * lda + k0 + c2;
-                if (al) a2v[v] = *reinterpret_cast<const double2*>(p); else { a2v[v].x = p[0]; a2v[v].y = p[1]; }
+            // Dinv arrives as 16-byte row pieces and goes through the LDS image first: its fragments are 8-byte pieces of
+            // 16 different rows per load instruction, and 32 such loads per lane kept the CU's vector cache busy for
+            // 3 us (entry -> operands staged 5.9 -> 2.9 us without them, tools/chol_stamps.py with -DEDRGP_PROBE_NODB)
+            double2 dv[8];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) dv[v] = *reinterpret_cast<const double2*>(Dinv + (size_t)(r8 + 8 * v) * NB + c2);
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        Cij[x][y][r] = Ct[(size_t)(i0 + 32 * wm + 16 * x + lq + 4 * r) * ldp + j0 + 32 * wn + 16 * y + lr];
+            if (ident) {                                     // block row k of C: still the identity, zero right of block k
+#pragma unroll
+                for (int v = 0; v < 8; ++v) {
+                    const int r = r8 + 8 * v;
+                    a1v[v].x = (r == c2) ? 1.0 : 0.0;
+                    a1v[v].y = (r == c2 + 1) ? 1.0 : 0.0;
+                }
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) Cij[x][y] = d4{0.0, 0.0, 0.0, 0.0};
             }
-            *reinterpret_cast<double2*>(&R[r * LS + c2]) = a1;
+#pragma unroll
+            for (int v = 0; v < 8; ++v) *reinterpret_cast<double2*>(&R[(r8 + 8 * v) * LS + c2]) = dv[v];
+            lds_barrier();
+#pragma unroll
+            for (int st = 0; st < 16; ++st)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) db[st][y] = R[(32 * wn + 16 * y + lr) * LS + 4 * st + lq];
+            lds_barrier();                                 // the image is free for tile i
+        } else {
+#pragma unroll
+            for (int st = 0; st < 16; ++st)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) db[st][y] = Dinv[(32 * wn + 16 * y + lr) * NB + 4 * st + lq];
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = i0 + 32 * wm + 16 * x + lq + 4 * r, col = j0 + 32 * wn + 16 * y + lr;
+                        Cij[x][y][r] = (!panel_only && !ident && row < n && col < n) ? Ct[(size_t)row * ldp + col] : 0.0;
+                    }
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                const int r = r8 + 8 * v;
+                double2 a1 = {0.0, 0.0};
+                a2v[v] = double2{0.0, 0.0};
+                if (ident) {
+                    a1.x = (r == c2) ? 1.0 : 0.0;
+                    a1.y = (r == c2 + 1) ? 1.0 : 0.0;
+                } else if (i0 + r < n) {
+                    // (the panel columns are whole except in the panel-only launch, whose block column may be ragged)
+                    const double* p = Pi + (size_t)(i0 + r) * ldp + k0 + c2;
+                    if (alp && k0 + c2 + 1 < n) a1 = *reinterpret_cast<const double2*>(p);
+                    else { a1.x = (k0 + c2 < n) ? p[0] : 0.0; a1.y = (k0 + c2 + 1 < n) ? p[1] : 0.0; }
+                }
+                if (two && j0 + r < n) {
+                    const double* p = A + (size_t)(j0 + r) * lda + k0 + c2;
+                    if (al) a2v[v] = *reinterpret_cast<const double2*>(p); else { a2v[v].x = p[0]; a2v[v].y = p[1]; }
+                }
+                a1v[v] = a1;
+            }
         }
+#pragma unroll
+        for (int v = 0; v < 8; ++v) *reinterpret_cast<double2*>(&R[(r8 + 8 * v) * LS + c2]) = a1v[v];
     }
-    __syncthreads();
+    lds_barrier();
+    if (tile == 0) CHOL_STAMP(1);
 
     // panel products on the matrix pipe: L_i = (tile i) Dinv^T, then L_j likewise through the same LDS image
     d4 Li[2][2], Lj[2][2];
@@ -459,11 +276,12 @@ __global__ __launch_bounds__(256, CAPPED ? 1 : 2) void chol_step_kernel(double* 
 #pragma unroll
             for (int y = 0; y < 2; ++y) Li[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[x], db[st][y], Li[x][y], 0, 0, 0);
     }
-    __syncthreads();                     // everyone has read tile i
+    lds_barrier();                     // everyone has read tile i
+    if (tile == 0) CHOL_STAMP(2);
     if (two) {
 #pragma unroll
         for (int v = 0; v < 8; ++v) *reinterpret_cast<double2*>(&R[(r8 + 8 * v) * LS + c2]) = a2v[v];
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int st = 0; st < 16; ++st) {
             double a2[2];
@@ -474,7 +292,7 @@ __global__ __launch_bounds__(256, CAPPED ? 1 : 2) void chol_step_kernel(double* 
 #pragma unroll
                 for (int y = 0; y < 2; ++y) Lj[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[x], db[st][y], Lj[x][y], 0, 0, 0);
         }
-        __syncthreads();                 // everyone has read tile j
+        lds_barrier();                 // everyone has read tile j
     }
     // L_i through LDS: its [row][k] image feeds the A fragments of the update (kept in registers) and the stores
 #pragma unroll
@@ -487,7 +305,7 @@ __global__ __launch_bounds__(256, CAPPED ? 1 : 2) void chol_step_kernel(double* 
                 R[row * LS + col] = Li[x][y][r];
                 if (!inv_tile && tj == 0 && i0 + row < n) Lout[(size_t)(i0 + row) * ldl + k0 + col] = Li[x][y][r];
             }
-    __syncthreads();
+    lds_barrier();
     if (inv_tile && tj == 0) {
         // finished block (ci, k) of L^-T -> block (k, ci) of L^-1, transposed through LDS: consecutive lanes write
         // consecutive columns of one row of Linv
@@ -499,20 +317,21 @@ __global__ __launch_bounds__(256, CAPPED ? 1 : 2) void chol_step_kernel(double* 
         }
     }
     if (panel_only) return;
+    if (tile == 0) CHOL_STAMP(3);
     double af[16][2];
 #pragma unroll
     for (int st = 0; st < 16; ++st)
 #pragma unroll
         for (int x = 0; x < 2; ++x) af[st][x] = R[(32 * wm + 16 * x + lr) * LS + 4 * st + lq];
     if (two) {
-        __syncthreads();                 // the A fragments (and the transposed store) are out of the image
+        lds_barrier();                 // the A fragments (and the transposed store) are out of the image
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
             for (int y = 0; y < 2; ++y)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) R[(32 * wm + 16 * x + lq + 4 * r) * LS + 32 * wn + 16 * y + lr] = Lj[x][y][r];
-        __syncthreads();
+        lds_barrier();
     }
     // the update: S = L_i L_j^T (diagonal tile: L_i L_i^T), B fragments from the image of L_j
     d4 S[2][2];
@@ -530,6 +349,7 @@ __global__ __launch_bounds__(256, CAPPED ? 1 : 2) void chol_step_kernel(double* 
 #pragma unroll
             for (int y = 0; y < 2; ++y) S[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[st][x], b[y], S[x][y], 0, 0, 0);
     }
+    if (tile == 0) CHOL_STAMP(4);
     next_diag = (Dinv_next != nullptr && tile == 0);
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -544,13 +364,13 @@ __global__ __launch_bounds__(256, CAPPED ? 1 : 2) void chol_step_kernel(double* 
     // next tile of this workgroup (workgroup 0 has none; an uncapped launch has one tile per workgroup)
     if (!CAPPED || blockIdx.x == 0) break;
     tile = (tile < G) ? G + ((int)blockIdx.x - 1) : tile + (G - 1);
-    __syncthreads();                     // the LDS image is reused
+    lds_barrier();                     // the LDS image is reused
     }   // tile loop
     // The workgroup of tile (k+1, k+1) has just produced the next diagonal block: it factors and inverts it on the
     // spot, straight out of its registers (no round trip through memory: the work matrix never needs this tile
     // again), so the next step needs no separate diagonal-block launch on the critical path.
     if (next_diag) {
-        __syncthreads();                 // every wave is done with the image of L_i
+        lds_barrier();                 // every wave is done with the image of L_i
         double (*Lt)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(Rbuf);      // Lt[k][i] = block[i][k], identity padded
         const int jb = min(NB, n - (k + 1) * NB);
 #pragma unroll
@@ -563,8 +383,15 @@ __global__ __launch_bounds__(256, CAPPED ? 1 : 2) void chol_step_kernel(double* 
                     const bool in = (row < jb) && (col < jb) && (col <= row);
                     Lt[col][row] = in ? Cij[x][y][r] : ((row == col) ? 1.0 : 0.0);
                 }
-        __syncthreads();
-        diag_block_body<true, true>(A, lda, n, k + 1, Dinv_next, nullptr, 0, info, nullptr, Lout, ldl, info_off, Rbuf);
+        lds_barrier();
+        CHOL_STAMP(5);
+#ifdef EDRGP_TILE_STAMPS
+        unsigned long long* body_stamps = (g_chol_stamps != nullptr && blockIdx.y == 0) ? g_chol_stamps + (size_t)k * 16 : nullptr;
+#else
+        unsigned long long* body_stamps = nullptr;
+#endif
+        diag_block_body<true, true>(A, lda, n, k + 1, Dinv_next, nullptr, 0, info, body_stamps, Lout, ldl, info_off, Rbuf);
+        CHOL_STAMP(6);
     }
 }
 
@@ -617,6 +444,15 @@ static int potrf_lower_fused(Ctx* c, double* A, int n, int lda, int* info_dev, b
         }
     }
     const int nblk = (n + NB - 1) / NB;
+#ifdef EDRGP_TILE_STAMPS
+    static unsigned long long* stamp_dev = nullptr;
+    const bool stamping = getenv("EDRGP_CHOL_STAMPS_FILE") != nullptr && nblk <= 64;
+    if (stamping) {
+        if (stamp_dev == nullptr) HIP_TRY(hipMalloc(&stamp_dev, 64 * 16 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(stamp_dev, 0, 64 * 16 * sizeof(unsigned long long), c->stream));
+        HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_chol_stamps), &stamp_dev, sizeof(stamp_dev), 0, hipMemcpyHostToDevice, c->stream));
+    }
+#endif
     hipLaunchKernelGGL(diag_block_kernel<true>, dim3(1, (unsigned)G), dim3(256), 0, c->stream, A, lda, n, 0, Dinv,
                        (double*)nullptr, 0, info_dev, (unsigned long long*)nullptr, Lw, n, info_off, bt);
     for (int b = 0; b + 1 < nblk; ++b) {
@@ -646,6 +482,14 @@ static int potrf_lower_fused(Ctx* c, double* A, int n, int lda, int* info_dev, b
     dim3 blk(64, 4), grd((n + 63) / 64, (n + 3) / 4, (unsigned)G);
     hipLaunchKernelGGL(take_lower_kernel, grd, blk, 0, c->stream, A, lda, Lw, n, n, bt.sA, bt.sL);
     HIP_TRY(hipGetLastError());
+#ifdef EDRGP_TILE_STAMPS
+    if (stamping) {         // every factorisation overwrites the file: the last one stays
+        std::vector<unsigned long long> hst(64 * 16);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(hst.data(), stamp_dev, hst.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (FILE* fp = fopen(getenv("EDRGP_CHOL_STAMPS_FILE"), "wb")) { fwrite(hst.data(), 8, hst.size(), fp); fclose(fp); }
+    }
+#endif
     return EDRGP_OK;
 }
 

@@ -244,7 +244,6 @@ int  edrgp_dbg_syrk32(edrgp_ctx* ctx, const float* K, int64_t N, int M, double* 
 int  edrgp_dbg_potrf(edrgp_ctx* ctx, double* A, int n, int* info);
 /* factor and inverse of the factor out of the same launches: A <- L, Linv <- L^-1 */
 int  edrgp_dbg_potrf_inv(edrgp_ctx* ctx, double* A, int n, int* info, double* Linv);
-int  edrgp_dbg_diag_stamps(edrgp_ctx* ctx, const double* A64x64, int do_chol, double* stamps6);
 int  edrgp_dbg_trtri(edrgp_ctx* ctx, const double* L, double* Linv, int n);
 int  edrgp_dbg_syrk(edrgp_ctx* ctx, const double* K, int64_t N, int M, double* Phi);
 /* times the production Phi = K^T K kernel alone on a device-generated K (bench.py "isolated" figure) */
