@@ -129,8 +129,14 @@ __global__ __launch_bounds__(256, CAPPED ? 1 : 2) void chol_step_kernel(double* 
         if (Linv != nullptr) Linv += z * bt.sI;
     }
     double* R = Rbuf;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: the k-step limits below branch uniformly
     const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lq = lane >> 4;
+    // Column blocks of a wave: {wn, 3 - wn} (16 columns each), not {2 wn, 2 wn + 1}.  Dinv is lower triangular, so
+    // the panel products  (tile) Dinv^T  need only the k-steps st < 4 (cb + 1) of column block cb; blocks {0, 3} and
+    // {1, 2} give both wave columns 20 of the 32 (k-step, block) pairs: 40 MFMAs per product instead of 64.
+    const int cb16[2] = {16 * wn, 16 * (3 - wn)};
+    const int klim[2] = {4 * (wn + 1), 4 * (4 - wn)};
 
     // A launch never has more workgroups than CUs (the host caps the grid): a step took 37 us instead of 28 as soon
     // as its tiles outnumbered the CUs and workgroup 0 -- the critical path: its tile, then the factorisation and
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(256, CAPPED ? 1 : 2) void chol_step_kernel(double* 
                 for (int y = 0; y < 2; ++y)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        Cij[x][y][r] = Ct[(size_t)(i0 + 32 * wm + 16 * x + lq + 4 * r) * ldp + j0 + 32 * wn + 16 * y + lr];
+                        Cij[x][y][r] = Ct[(size_t)(i0 + 32 * wm + 16 * x + lq + 4 * r) * ldp + j0 + cb16[y] + lr];
             if (ident) {                                     // block row k of C: still the identity, zero right of block k
 #pragma unroll
                 for (int v = 0; v < 8; ++v) {
@@ -217,20 +223,20 @@ __global__ __launch_bounds__(256, CAPPED ? 1 : 2) void chol_step_kernel(double* 
 #pragma unroll
             for (int st = 0; st < 16; ++st)
 #pragma unroll
-                for (int y = 0; y < 2; ++y) db[st][y] = R[(32 * wn + 16 * y + lr) * LS + 4 * st + lq];
+                for (int y = 0; y < 2; ++y) db[st][y] = (st < klim[y]) ? R[(cb16[y] + lr) * LS + 4 * st + lq] : 0.0;
             lds_barrier();                                 // the image is free for tile i
         } else {
 #pragma unroll
             for (int st = 0; st < 16; ++st)
 #pragma unroll
-                for (int y = 0; y < 2; ++y) db[st][y] = Dinv[(32 * wn + 16 * y + lr) * NB + 4 * st + lq];
+                for (int y = 0; y < 2; ++y) db[st][y] = Dinv[(cb16[y] + lr) * NB + 4 * st + lq];
 #pragma unroll
             for (int x = 0; x < 2; ++x)
 #pragma unroll
                 for (int y = 0; y < 2; ++y)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int row = i0 + 32 * wm + 16 * x + lq + 4 * r, col = j0 + 32 * wn + 16 * y + lr;
+                        const int row = i0 + 32 * wm + 16 * x + lq + 4 * r, col = j0 + cb16[y] + lr;
                         Cij[x][y][r] = (!panel_only && !ident && row < n && col < n) ? Ct[(size_t)row * ldp + col] : 0.0;
                     }
 #pragma unroll
@@ -272,9 +278,11 @@ __global__ __launch_bounds__(256, CAPPED ? 1 : 2) void chol_step_kernel(double* 
 #pragma unroll
         for (int x = 0; x < 2; ++x) a1[x] = R[(32 * wm + 16 * x + lr) * LS + 4 * st + lq];
 #pragma unroll
-        for (int x = 0; x < 2; ++x)
+        for (int y = 0; y < 2; ++y)
+            if (st < klim[y]) {
 #pragma unroll
-            for (int y = 0; y < 2; ++y) Li[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[x], db[st][y], Li[x][y], 0, 0, 0);
+                for (int x = 0; x < 2; ++x) Li[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[x], db[st][y], Li[x][y], 0, 0, 0);
+            }
     }
     lds_barrier();                     // everyone has read tile i
     if (tile == 0) CHOL_STAMP(2);
@@ -288,9 +296,11 @@ __global__ __launch_bounds__(256, CAPPED ? 1 : 2) void chol_step_kernel(double* 
 #pragma unroll
             for (int x = 0; x < 2; ++x) a2[x] = R[(32 * wm + 16 * x + lr) * LS + 4 * st + lq];
 #pragma unroll
-            for (int x = 0; x < 2; ++x)
+            for (int y = 0; y < 2; ++y)
+                if (st < klim[y]) {
 #pragma unroll
-                for (int y = 0; y < 2; ++y) Lj[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[x], db[st][y], Lj[x][y], 0, 0, 0);
+                    for (int x = 0; x < 2; ++x) Lj[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[x], db[st][y], Lj[x][y], 0, 0, 0);
+                }
         }
         lds_barrier();                 // everyone has read tile j
     }
@@ -301,7 +311,7 @@ __global__ __launch_bounds__(256, CAPPED ? 1 : 2) void chol_step_kernel(double* 
         for (int y = 0; y < 2; ++y)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = 32 * wm + 16 * x + lq + 4 * r, col = 32 * wn + 16 * y + lr;
+                const int row = 32 * wm + 16 * x + lq + 4 * r, col = cb16[y] + lr;
                 R[row * LS + col] = Li[x][y][r];
                 if (!inv_tile && tj == 0 && i0 + row < n) Lout[(size_t)(i0 + row) * ldl + k0 + col] = Li[x][y][r];
             }
@@ -330,7 +340,7 @@ __global__ __launch_bounds__(256, CAPPED ? 1 : 2) void chol_step_kernel(double* 
 #pragma unroll
             for (int y = 0; y < 2; ++y)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) R[(32 * wm + 16 * x + lq + 4 * r) * LS + 32 * wn + 16 * y + lr] = Lj[x][y][r];
+                for (int r = 0; r < 4; ++r) R[(32 * wm + 16 * x + lq + 4 * r) * LS + cb16[y] + lr] = Lj[x][y][r];
         lds_barrier();
     }
     // the update: S = L_i L_j^T (diagonal tile: L_i L_i^T), B fragments from the image of L_j
@@ -343,7 +353,7 @@ __global__ __launch_bounds__(256, CAPPED ? 1 : 2) void chol_step_kernel(double* 
     for (int st = 0; st < 16; ++st) {
         double b[2];
 #pragma unroll
-        for (int y = 0; y < 2; ++y) b[y] = R[(32 * wn + 16 * y + lr) * LS + 4 * st + lq];
+        for (int y = 0; y < 2; ++y) b[y] = R[(cb16[y] + lr) * LS + 4 * st + lq];
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -357,7 +367,7 @@ __global__ __launch_bounds__(256, CAPPED ? 1 : 2) void chol_step_kernel(double* 
         for (int y = 0; y < 2; ++y)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = i0 + 32 * wm + 16 * x + lq + 4 * r, col = j0 + 32 * wn + 16 * y + lr;
+                const int row = i0 + 32 * wm + 16 * x + lq + 4 * r, col = j0 + cb16[y] + lr;
                 Cij[x][y][r] -= S[x][y][r];
                 if (!next_diag && row < n && col < n) Ct[(size_t)row * ldp + col] = Cij[x][y][r];
             }
@@ -379,7 +389,7 @@ __global__ __launch_bounds__(256, CAPPED ? 1 : 2) void chol_step_kernel(double* 
             for (int y = 0; y < 2; ++y)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = 32 * wm + 16 * x + lq + 4 * r, col = 32 * wn + 16 * y + lr;
+                    const int row = 32 * wm + 16 * x + lq + 4 * r, col = cb16[y] + lr;
                     const bool in = (row < jb) && (col < jb) && (col <= row);
                     Lt[col][row] = in ? Cij[x][y][r] : ((row == col) ? 1.0 : 0.0);
                 }
