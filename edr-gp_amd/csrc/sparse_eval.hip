@@ -340,7 +340,8 @@ struct SparseEval {
             TRY(combine3(c, M, beta, Phi, 0.0, nullptr, 0.0, nullptr, 0.0, nullptr, A));
             HIP_TRY(hipMemcpyAsync(v_v, bvec, (size_t)M * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         } else {
-            TRY(gemm(c, false, false, M, M, M, 1.0, Li, M, Phi, M, 0.0, Tm, M, kopt(K_LE_ROW)));
+            // Tm = Li Phi: A's lower tiles (i, j) read Tm[i][k] for k <= j <= i only, so the lower tiles of Tm suffice
+            TRY(gemm(c, false, false, M, M, M, 1.0, Li, M, Phi, M, 0.0, Tm, M, kopt(K_LE_ROW, 1)));
             // A = beta (Li Phi) Li^T is symmetric: lower tiles only, then mirrored
             GemmOpts oa = kopt(K_LE_COL, 1);
             oa.mirror_out = 1;
