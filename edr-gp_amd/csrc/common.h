@@ -182,6 +182,9 @@ int kernel_matrix(Ctx* c, const KSpec& ks, const double* X, int64_t rows, const 
 int grad_elementwise(Ctx* c, const KSpec& ks, int part, const double* X, const double* y, int64_t rows,
                      const double* Z, int M, const double* W, int ldw, double ycoef, const double* wv,
                      double* T, int ldt, double* dvar_accum /* device scalar, += */);
+// Kmm term, single-part kernels: T = dK .* Hz, dvar_accum += sum dK .* Kz / var (Kz, Hz: K(Z, Z) and h(r) of the MFMA build)
+int kmm_term_elementwise(Ctx* c, const double* dK, const double* Kz, const double* Hz, int Mr, int M, double var,
+                         double* T, double* dvar_accum);
 // Xt = [X | 1 | X.*X]  (rows x (2D+1))
 int build_xtilde(Ctx* c, const double* X, int64_t rows, int D, double* Xt);
 int build_xq(Ctx* c, const double* X, int64_t rows, int D, double* Xq);               // [X | X.^2]

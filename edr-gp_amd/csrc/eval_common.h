@@ -22,6 +22,8 @@ enum {  // c->mats
     MAT_C1,       // scratch
     MAT_DKMM,     // dL/dKmm
     MAT_TMM,      // element-wise factor for the Kmm term
+    MAT_KZ,       // K(Z, Z) without jitter and
+    MAT_HZ,       // h(r(Z, Z)) for the Kmm term of single-part kernels
 };
 
 enum {  // device scalar slots (c->scal)

@@ -116,6 +116,8 @@ struct SparseEval {
     int fin_blocks = 0;
     bool h_built = false;         // the K_nm chunk in c->Knm has its h(r) companion in c->Hnm
     bool tma_done = false;        // Lm^-T A Lm^-1 (Kmm term) was formed on the side stream beside the factorisation of B
+    bool kz_done = false;         // K(Z, Z) and h(r) for the element-wise Kmm term are in MAT_KZ / MAT_HZ
+    bool kmm_chain_queued = false;
     bool k32_resident = false;
     // precision 32 asks for the fp32 row pass; it is used while the Gram form is safe in fp32 (error ~ eps32
     // cond(Kmm), judged by the pivot-ratio proxy after phase 1), otherwise this evaluation falls back to the fp64
@@ -155,7 +157,7 @@ struct SparseEval {
         beta = 1.0 / std::max(c->noise_var, 1e-8);
         ks = make_kspec(c);
         TRY(get_globals(c, &gl));
-        TRY(ensure_mats(c, M, need_grad ? 14 : (need_post ? 10 : 7)));
+        TRY(ensure_mats(c, M, need_grad ? 16 : (need_post ? 10 : 7)));
         chunk = std::min<int64_t>(N, std::max<int64_t>(64, c->chunk_rows));
         nchunks = (N + chunk - 1) / chunk;
         // 16 spare rows: the row count handed to the Phi kernel is rounded up to whole k-tiles with zero rows
@@ -181,7 +183,7 @@ struct SparseEval {
         f32 = want32 && c->f32_phi && !c->phi32_bad;
         // the fused one-launch-per-step factorisation covers n in (64, 3072]; outside it the explicit inverse stays
         rhs_row = !need_grad && !need_post && c->chol_rhs && c->chol_fused && M > 64 && M + 1 <= 3072;
-        k_resident = prebuilt = kmmi_done = kmmi_pending = tma_done = k32_resident = h_built = false;
+        k_resident = prebuilt = kmmi_done = kmmi_pending = tma_done = k32_resident = h_built = kz_done = kmm_chain_queued = false;
         return EDRGP_OK;
     }
 
@@ -211,6 +213,10 @@ struct SparseEval {
             TRY(potrf_inv_lower(c, Lm, M, M, info + 0, Li, M));
         }
         TRY(diag_minmax(c, Lm, Mr, M, sc + SC_DIAGMIN));
+        // gradient evaluations: K(Z, Z) and h(r) for the element-wise Kmm term, behind the factorisation (phase 1 ends
+        // before the K_nm build it runs beside; beside the factorisation of B the same launch cost that chain 0.25 ms,
+        // in the tail of the evaluation it took 420 us beside T^T [X | X.^2])
+        if (need_grad && np == 1 && c->mfma_kbuild && !kz_done) TRY(build_kz());
         return EDRGP_OK;
     }
     // careful driver: GPy's jitchol ladder, one synchronisation per attempt
@@ -439,6 +445,15 @@ struct SparseEval {
         return EDRGP_OK;
     }
 
+    // K(Z, Z) without jitter and its h(r) for the element-wise Kmm term (35 us alone; queued at the end of phase 1)
+    int build_kz() {
+        c->kbuild_h = c->mats[MAT_HZ].d();
+        const int st = kernel_matrix(c, ks, c->Z.d(), Mr, c->Z.d(), Mr, c->mats[MAT_KZ].d(), M, 1, 0.0, nullptr, nullptr);
+        c->kbuild_h = nullptr;
+        if (st == EDRGP_OK) kz_done = true;
+        return st;
+    }
+
     // The two M^3 products of the Kmm term that need A but not LB (C1 = Li^T A, Lm^-T A Lm^-1 = C1 Li) join Kmm^-1 on
     // the side stream beside the factorisation of B.  They used to run beside the gradient contraction, which as a
     // persistent grid leaves no slot to a second kernel: the whole Kmm chain then ran after it (1.2 ms at Cm).
@@ -515,6 +530,12 @@ struct SparseEval {
         // dL/dKmm = 1/2 Kmm^-1 - 1/2 P - 1/2 wv wv^T - 1/2 Lm^-T A Lm^-1
         TRY(combine3(c, M, 0.5, Kmmi, -0.5, P, -0.5, LtAL, -0.5, v_wv, dKmm));
         for (int p = 0; p < np; ++p) {
+            if (np == 1 && c->mfma_kbuild) {
+                // k and h(r) of K(Z, Z) from the MFMA build, then one element-wise pass
+                if (!kz_done) TRY(build_kz());
+                TRY(kmm_term_elementwise(c, dKmm, c->mats[MAT_KZ].d(), c->mats[MAT_HZ].d(), Mr, M, c->var[0], Tmm,
+                                         sc + SC_DVAR_MM));
+            } else
             TRY(grad_elementwise(c, ks, p, c->Z.d(), nullptr, M, c->Z.d(), M, dKmm, M, 0.0, nullptr, Tmm, M,
                                  sc + SC_DVAR_MM + p));
             TRY(gemm(c, true, false, M, Wd, M, 1.0, Tmm, M, c->Zt.d(), Wd, 0.0,
@@ -522,6 +543,28 @@ struct SparseEval {
             TRY(gemm(c, false, false, M, Wd, M, 1.0, Tmm, M, c->Zt.d(), Wd, 0.0,
                      c->gt_mm.d() + (size_t)(2 * p + 1) * M * Wd, Wd));
         }
+        return EDRGP_OK;
+    }
+
+    // rows of the leading row tiles that fill whole rounds of the persistent contraction grid (2 workgroups per CU);
+    // `rows` when there is nothing to split off
+    int64_t contraction_whole_rounds(int64_t rows) const {
+        if (!c->overlap || !c->gemm_persist || M < 128) return rows;
+        const int64_t tn = (M + 127) / 128, tm = (rows + 127) / 128, grid = 2 * (int64_t)c->num_cu;
+        const int64_t rounds = tm * tn / grid;
+        const int64_t tmA = rounds * grid / tn;
+        if (rounds < 2 || tmA <= 0 || tmA >= tm) return rows;
+        return tmA * 128;
+    }
+
+    // The Kmm-term chain on the side stream, released by whatever the main stream has queued so far
+    int queue_kmm_chain() {
+        if (!c->overlap || kmm_chain_queued) return EDRGP_OK;
+        SideStream side(c);
+        TRY(side.start_after_main());
+        TRY(kmm_term_queue());
+        TRY(side.mark_done());
+        kmm_chain_queued = true;
         return EDRGP_OK;
     }
 
@@ -601,7 +644,26 @@ struct SparseEval {
                 o.tag = 2;
                 o.force_tile = 128;
                 o.fuse = &f;
-                TRY(gemm(c, false, false, (int)rows, M, M, 1.0, c->Knm.d(), M, S2, M, 0.0, c->T.d(), M, o));
+                // The launch is a persistent grid of 2 workgroups per CU that holds every workgroup slot; its last,
+                // partial round of tiles leaves half the CUs idle (Cm: 224 tiles, 0.46 ms).  That round is a launch
+                // of its own -- the last row tiles -- and the Kmm-term chain (side stream, 0.2 ms) is released when
+                // the whole rounds are done: it runs in the idle half beside the remainder instead of queueing for
+                // slots through the whole contraction (its first kernel showed 12 ms in the kernel statistics).
+                const int64_t rowsA = (ch == nchunks - 1) ? contraction_whole_rounds(rows) : rows;
+                TRY(gemm(c, false, false, (int)rowsA, M, M, 1.0, c->Knm.d(), M, S2, M, 0.0, c->T.d(), M, o));
+                if (ch == nchunks - 1) TRY(queue_kmm_chain());
+                if (rowsA < rows) {
+                    FuseT fb = f;
+                    const size_t tA = (size_t)(rowsA / 128);
+                    fb.X += (size_t)rowsA * D; fb.y += rowsA;
+                    fb.dvpart += tA * ((M + 127) / 128);
+                    fb.cspart += tA * M;
+                    if (fb.K != nullptr) fb.K += (size_t)rowsA * M;
+                    if (fb.H != nullptr) fb.H += (size_t)rowsA * M;
+                    o.fuse = &fb;
+                    TRY(gemm(c, false, false, (int)(rows - rowsA), M, M, 1.0, c->Knm.d() + (size_t)rowsA * M, M, S2, M, 0.0,
+                             c->T.d() + (size_t)rowsA * M, M, o));
+                }
                 TRY(sum_into(c, c->red.d(), ntiles, sc + SC_DVAR_NM));
                 TRY(col_reduce(c, c->bpart.d(), tiles_m, M, csv));
                 TRY(gemm(c, true, false, M, 2 * D, (int)rows, 1.0, c->T.d(), M, c->Xq.d() + (size_t)r0 * 2 * D, 2 * D, 0.0, G2,
@@ -635,19 +697,23 @@ struct SparseEval {
             TRY(combine3(c, M, beta, c->mats[MAT_KMMI].d(), -beta, c->mats[MAT_P].d(), 0.0, nullptr, -beta, v_wv, S2));
         }
         TRY(c->gt_mm.reserve((size_t)2 * np * M * Wd * sizeof(double)));
-        if (c->overlap) {
-            SideStream side(c);
-            int st = side.start_after_main();
-            if (st == EDRGP_OK) st = kmm_term_queue();
-            if (st == EDRGP_OK) st = side.mark_done();
-            if (st != EDRGP_OK) return st;
-        }
         TRY(c->gt_nm.reserve((size_t)np * M * Wd * sizeof(double)));
+        {
+            // the fused fp64 row pass releases the Kmm-term chain beside its last launch; every other path queues it
+            // in front of the row pass
+            const bool fused_expected = !g32 && (np == 1) && c->fuse_grad &&
+                                        (D <= 32 || (c->kind[0] == EDRGP_KERN_RBF && c->rbf_epilogue) || want_h());
+            if (!fused_expected) TRY(queue_kmm_chain());
+        }
         if (g32) TRY(grad_rows32_queue(S2));
         else TRY(grad_rows64_queue(S2));
         tr.mark("grad queued");
-        if (c->overlap) TRY(main_waits_side(c));
-        else TRY(kmm_term_queue());
+        if (c->overlap) {
+            TRY(queue_kmm_chain());              // (paths that did not release it beside their last launch)
+            TRY(main_waits_side(c));
+        } else {
+            TRY(kmm_term_queue());
+        }
         if (c->sharded()) {
             TRY(allreduce_sum(c, c->gt_nm.d(), (size_t)np * M * Wd));
             TRY(allreduce_sum(c, sc + SC_DVAR_NM, EDRGP_MAX_PARTS));
