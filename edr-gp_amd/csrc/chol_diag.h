@@ -6,12 +6,12 @@
 // The block is the critical path of the whole factorisation (2048 serial pivots at n = 2048, 32 block boundaries),
 // so the body is organised around the chain of pivots:
 //
-//  * Block column w (16 columns) belongs to wave w.  Wave 0 starts on its pivots at once; wave w > 0 holds its part
-//    of the trailing matrix in MFMA C/D tiles, applies the rank-16 update of every finished panel s < w as soon as
-//    that panel's barrier falls (4 MFMAs per tile, fragments straight from the [k][row] image of L in LDS), then
-//    brings its panel into "one row per lane" registers for its own 16 pivots.  On the critical path between two
-//    panels are only the update of the NEXT block column (3 / 2 / 1 tiles) and one transposition through LDS; the
-//    single-wave form updated all remaining tiles (6 / 3 / 1) in line.
+//  * The 16 pivots of block column w (16 columns) run on wave w, which holds that panel as one row per lane.  The
+//    trailing matrix lives in MFMA C/D tiles, row block i on wave i; when a panel's barrier falls every wave first
+//    brings its tile of the NEXT block column up to date (4 MFMAs, fragments straight from the [k][row] image of L
+//    in LDS) and writes it into the panel image, a second barrier, and the next wave reads its panel and starts.  On
+//    the critical path between two panels: one tile update, one transposition through LDS (the single-wave form
+//    updated all 6 / 3 / 1 remaining tiles in line).
 //  * A pivot is a wave-uniform chain  pv -> 1/sqrt(pv) -> next pv  on values fetched with v_readlane BEFORE the
 //    reciprocal square root is known (the entries (j+1, j) and (j+1, j+1) of the panel), so no cross-lane traffic and
 //    no LDS round trip sits on it; the rank-1 update of the panel's other columns (one v_fma_f64 per column, the
@@ -25,7 +25,7 @@
 //    X_ij = -T_i sum_{k=j}^{i-1} L_ik X_kj on the matrix pipe, accumulator tiles used directly as the next
 //    product's B operand; the sum is formed while panel i is still being factored (it needs L_ik, k < i, only), so
 //    after the last pivot the whole inverse is 4 MFMAs and a store away (it used to be a separate phase of 7.5k cycles).
-//  * One workgroup barrier per panel (LDS counters only: outstanding global stores are not waited for).
+//  * Seven workgroup barriers, all of them on LDS counters only (outstanding global stores are not waited for).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -45,7 +45,8 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // 16 w .. 16 w + 15 of Pn, which only wave w itself ever uses as panel image) | rdiag[64] (inverse-only path): 42.5 KB,
 // so that a workgroup carrying it fits into the LDS one retiring workgroup of the padded K_nm build leaves free on a
 // CU -- see chol_step_kernel
-constexpr int DIAG_LDS = NB * (NB + 1) + 4 * 16 * 17 + NB;
+constexpr int LTS = NB + 2;          // row stride of the image Lt[k][row]: even, so that pairs of broadcast multipliers are 16-byte aligned (ds_read_b128, immediate offsets)
+constexpr int DIAG_LDS = NB * LTS + 4 * 16 * 17 + NB;
 
 // workgroup barrier that orders LDS traffic only
 __device__ __forceinline__ void lds_barrier() {
@@ -71,57 +72,18 @@ struct DiagOut {
     unsigned long long* stamps;
 };
 
-// The program of wave W (see the header comment).  `Lt` holds the lower triangle of the block as Lt[col][row],
-// identity padded beyond jb, zero above the diagonal; every wave runs the same four barriers.
+// The 16 pivots of panel W on the wave that holds it as one row per lane (see the header comment)
 template <int W>
-__device__ __forceinline__ void diag_wave_program(double (*Lt)[NB + 1], double (*Pn)[17], double (*Tl)[16][17],
-                                                  const int lane, const DiagOut& o) {
+__device__ __forceinline__ void diag_panel_pivots(double (*Lt)[LTS], const int lane, double (&p)[16], double (&yv)[16]) {
     constexpr int OFF = 16 * W;
-    const int lr = lane & 15, lq = lane >> 4;
-    double p[16];
-    double yv[16];                       // W == 0 only: 1 / L[j][j] for the substitution
-    d4 T[4];                             // W > 0: tiles (i, W), i >= W, of the trailing matrix, C/D layout
-    if (W == 0) {
-#pragma unroll
-        for (int cc = 0; cc < 16; ++cc) p[cc] = Lt[cc][lane];
-    } else {
-#pragma unroll
-        for (int i = W; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) T[i][r] = Lt[OFF + lr][16 * i + lq + 4 * r];
-    }
-    // rank-16 updates of the finished panels
-#pragma unroll
-    for (int s = 0; s < W; ++s) {
-        lds_barrier();                   // panel s is in Lt
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            const double bf = Lt[16 * s + 4 * st + lq][OFF + lr];
-#pragma unroll
-            for (int i = W; i < 4; ++i) {
-                const double af = -Lt[16 * s + 4 * st + lq][16 * i + lr];
-                T[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, T[i], 0, 0, 0);
-            }
-        }
-    }
-    if (W > 0) {
-        // the panel -> one row per lane; lanes 0..15 take the identity (the inverse of the diagonal block rides along)
-#pragma unroll
-        for (int i = W; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Pn[16 * i + lq + 4 * r][lr] = T[i][r];
-        wave_lds_order();
-#pragma unroll
-        for (int cc = 0; cc < 16; ++cc) p[cc] = (lane >= OFF) ? Pn[lane][cc] : ((lane == cc) ? 1.0 : 0.0);
-    }
-    // The 16 pivots.  Per pivot j (column jj of the panel): the wave-uniform chain, l = column jj scaled, and the rank-1
-    // update of the columns to its right, p[kk] -= l * L[OFF + kk][j].  The multipliers L[OFF + kk][j] are entries of l
-    // in other lanes.  For kk = jj + 1, jj + 2 -- needed by the very next pivots -- they are formed from values fetched
-    // with v_readlane before y is known (a1 y, a2 y: no dependence on l).  For kk >= jj + 3 they come back from the
-    // column just written to LDS as broadcast reads, and are CONSUMED ONE PIVOT LATER (cm[], lprev): an LDS write ->
-    // read round trip is 85 cycles and a broadcast read costs a lone wave ~19 cycles of LDS -> register traffic, so
-    // taking them in the same iteration put 85 + 19 (15 - jj) cycles in front of the next v_rsq_f64 (370 cycles per
-    // pivot, tools/diag_probe.hip); one iteration later they have arrived while the next chain was being issued.
+    // Per pivot j (column jj of the panel): the wave-uniform chain, l = column jj scaled, and the rank-1 update of the
+    // columns to its right, p[kk] -= l * L[OFF + kk][j].  The multipliers L[OFF + kk][j] are entries of l in other
+    // lanes.  For kk = jj + 1, jj + 2 -- needed by the very next pivots -- they are formed from values fetched with
+    // v_readlane before y is known (a1 y, a2 y: no dependence on l).  For kk >= jj + 3 they come back from the column
+    // just written to LDS as broadcast reads, and are CONSUMED ONE PIVOT LATER (cm[], lprev): an LDS write -> read
+    // round trip is 85 cycles and a broadcast read costs a lone wave ~19 cycles of LDS -> register traffic, so taking
+    // them in the same iteration put 85 + 19 (15 - jj) cycles in front of the next v_rsq_f64 (370 cycles per pivot,
+    // tools/diag_probe.hip); one iteration later they have arrived while the next chain was being issued (256).
     double pv = readlane_f64(p[0], OFF);
     double cm[16];                       // multipliers of the previous pivot for the columns it has not updated yet
     double lprev = 0.0;
@@ -156,84 +118,156 @@ __device__ __forceinline__ void diag_wave_program(double (*Lt)[NB + 1], double (
             for (int kk = jj + 2; kk < 16; ++kk) p[kk] = fma(-lprev, cm[kk], p[kk]);
         }
         wave_lds_order();
+        // (16-byte reads of aligned pairs: the image's row stride is even)
+        if (((jj + 3) & 1) && jj + 3 < 16) cm[jj + 3] = Lt[j][OFF + jj + 3];
 #pragma unroll
-        for (int kk = jj + 3; kk < 16; ++kk) cm[kk] = Lt[j][OFF + kk];
+        for (int kk = (jj + 4) & ~1; kk < 16; kk += 2) {
+            const double2 v = *reinterpret_cast<const double2*>(&Lt[j][OFF + kk]);
+            cm[kk] = v.x;
+            cm[kk + 1] = v.y;
+        }
         lprev = l;
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (W > 0 && lane < 16) {
-        // lane c holds column c of T_W = inv(L_WW): reg i = T[i][c]
-#pragma unroll
-        for (int i = 0; i < 16; ++i) Tl[W][i][lane] = p[i];
-    }
-    lds_barrier();                       // barrier W: panel W (and T_W) are in LDS
-    if (o.stamps != nullptr && lane == 0) o.stamps[8 + W] = __builtin_amdgcn_s_memtime();
+}
 
-    // the factor's block column W goes out (fire and forget: the barriers below do not wait for global stores)
-    {
-        const int row = lane;
-        if (row < o.jb) {
-            double* dst = o.Lw + (size_t)row * o.ldw + OFF;
-            if (o.vec && OFF + 16 <= o.jb) {
-#pragma unroll
-                for (int cc = 0; cc < 16; cc += 2) {
-                    double2 v;
-                    v.x = (row >= OFF + cc) ? p[cc] : 0.0;
-                    v.y = (row >= OFF + cc + 1) ? p[cc + 1] : 0.0;
-                    *reinterpret_cast<double2*>(dst + cc) = v;
-                }
-            } else {
-#pragma unroll
-                for (int cc = 0; cc < 16; ++cc)
-                    if (OFF + cc < o.jb) dst[cc] = (row >= OFF + cc) ? p[cc] : 0.0;
-            }
-        }
-    }
-
-    // ---- inverse: block column W
-    if (W == 0) {
-        // T_0 = inv(L_00) by substitution (lane 16 b + c: column c; the four lane groups repeat the same work)
-        double t[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) t[i] = (i == lr) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            t[k] *= yv[k];
-            const double tk = t[k];
-#pragma unroll
-            for (int i = k + 1; i < 16; ++i) t[i] = fma(-Lt[k][i], tk, t[i]);
-        }
-        if (lane < 16) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) Tl[0][i][lane] = t[i];
-        }
-        wave_lds_order();
-    }
+// The program of wave W (see the header comment).  `Lt` holds the lower triangle of the block as Lt[col][row],
+// identity padded beyond jb, zero above the diagonal.  Every wave runs the same seven barriers: B(s) when panel s is
+// factored, B'(s) when the image of panel s + 1 is complete.
+//   Wave W owns row block W of the trailing matrix -- the tiles (W, b), 1 <= b <= W, in MFMA C/D layout -- and block
+//   column W of the inverse.  After B(s) every wave W > s first brings its tile of block column s + 1 up to date with
+//   panel s (4 MFMAs, fragments from the [k][row] image of L) and writes it into the panel image; after B'(s) wave
+//   s + 1 reads that image as one row per lane and starts on its pivots, while the others update their remaining
+//   tiles.  On the critical path between two panels: 8 fragment reads, 4 MFMAs, 4 LDS writes, a barrier and 16 LDS
+//   reads (when one wave updated all tiles of the next block column itself it was 16 + 12 + 12 + 16).
+template <int W>
+__device__ __forceinline__ void diag_wave_program(double (*Lt)[LTS], double (*Pn)[17], double (*Tl)[16][17],
+                                                  const int lane, const DiagOut& o) {
+    constexpr int OFF = 16 * W;
+    const int lr = lane & 15, lq = lane >> 4;
+    double p[16];
+    double yv[16];                       // W == 0 only: 1 / L[j][j] for the substitution
+    d4 T[4];                             // T[b] = tile (W, b), 1 <= b <= W
     d4 X[4];                             // X[i] = X_iW, i >= W, C/D layout: reg r = row lq + 4 r, col lr
+    d4 S = {0.0, 0.0, 0.0, 0.0};
+    if (W == 0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) X[W][r] = Tl[W][lq + 4 * r][lr];
+        for (int cc = 0; cc < 16; ++cc) p[cc] = Lt[cc][lane];
+    } else {
 #pragma unroll
-    for (int i = W + 1; i < 4; ++i) {
-        d4 S = {0.0, 0.0, 0.0, 0.0};
+        for (int b = 1; b <= W; ++b)
 #pragma unroll
-        for (int k = W; k < i; ++k)
+            for (int r = 0; r < 4; ++r) T[b][r] = Lt[16 * b + lr][OFF + lq + 4 * r];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        // ---- in front of barrier B(s)
+        if (s == W) {
+            diag_panel_pivots<W>(Lt, lane, p, yv);
+            if (W > 0 && lane < 16) {
+                // lane c holds column c of T_W = inv(L_WW): reg i = T[i][c]
+#pragma unroll
+                for (int i = 0; i < 16; ++i) Tl[W][i][lane] = p[i];
+            }
+        } else if (s > W) {
+            // block (s, W) of the inverse, first half: S = sum_k L_sk X_kW (L_sk, k < s, is final since B(s - 1))
+            S = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = W; k < s; ++k)
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const double af = Lt[16 * k + 4 * st + lq][16 * s + lr];        // L[16 s + lr][16 k + 4 st + lq]
+                    S = __builtin_amdgcn_mfma_f64_16x16x4f64(af, X[k][st], S, 0, 0, 0);
+                }
+        }
+        lds_barrier();                   // B(s): panel s (and T_s) are in LDS
+        if (o.stamps != nullptr && lane == 0 && s == W) o.stamps[8 + W] = __builtin_amdgcn_s_memtime();
+        double af[4];
+        if (s < 3) {
+            if (W > s) {
+                // urgent: this wave's tile of block column s + 1, then into the panel image
+#pragma unroll
+                for (int st = 0; st < 4; ++st) af[st] = -Lt[16 * s + 4 * st + lq][OFF + lr];
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const double bf = Lt[16 * s + 4 * st + lq][16 * (s + 1) + lr];
+                    T[s + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[st], bf, T[s + 1], 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Pn[OFF + lq + 4 * r][lr] = T[s + 1][r];
+            }
+            lds_barrier();               // B'(s): the image of panel s + 1 is complete
+        }
+        // ---- off the critical path
+        if (s == W) {
+            // the factor's block column W goes out (fire and forget: the barriers do not wait for global stores)
+            const int row = lane;
+            if (row < o.jb) {
+                double* dst = o.Lw + (size_t)row * o.ldw + OFF;
+                if (o.vec && OFF + 16 <= o.jb) {
+#pragma unroll
+                    for (int cc = 0; cc < 16; cc += 2) {
+                        double2 v;
+                        v.x = (row >= OFF + cc) ? p[cc] : 0.0;
+                        v.y = (row >= OFF + cc + 1) ? p[cc + 1] : 0.0;
+                        *reinterpret_cast<double2*>(dst + cc) = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int cc = 0; cc < 16; ++cc)
+                        if (OFF + cc < o.jb) dst[cc] = (row >= OFF + cc) ? p[cc] : 0.0;
+                }
+            }
+            if (W == 0) {
+                // T_0 = inv(L_00) by substitution (lane 16 b + c: column c; the four lane groups repeat the same work)
+                double t[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) t[i] = (i == lr) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    t[k] *= yv[k];
+                    const double tk = t[k];
+#pragma unroll
+                    for (int i = k + 1; i < 16; ++i) t[i] = fma(-Lt[k][i], tk, t[i]);
+                }
+                if (lane < 16) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) Tl[0][i][lane] = t[i];
+                }
+                wave_lds_order();
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) X[W][r] = Tl[W][lq + 4 * r][lr];
+        } else if (s > W) {
+            // block (s, W) of the inverse, second half: X_sW = -T_s S
+            d4 Y = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
-                // A fragment of L_ik: lane holds L[16 i + lr][16 k + 4 st + lq]
-                const double af = Lt[16 * k + 4 * st + lq][16 * i + lr];
-                S = __builtin_amdgcn_mfma_f64_16x16x4f64(af, X[k][st], S, 0, 0, 0);
+                const double tf = -Tl[s][lr][4 * st + lq];           // A fragment of -T_ss
+                Y = __builtin_amdgcn_mfma_f64_16x16x4f64(tf, S[st], Y, 0, 0, 0);
             }
-        lds_barrier();                   // barrier i: T_i is in LDS
-        d4 Y = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            const double tf = -Tl[i][lr][4 * st + lq];           // A fragment of -T_ii
-            Y = __builtin_amdgcn_mfma_f64_16x16x4f64(tf, S[st], Y, 0, 0, 0);
+            X[s] = Y;
         }
-        X[i] = Y;
+        if (s < 3) {
+            if (W == s + 1) {
+                // the panel as one row per lane; lanes 0..15 take the identity (the inverse of the diagonal block
+                // rides along)
+#pragma unroll
+                for (int cc = 0; cc < 16; ++cc) p[cc] = (lane >= OFF) ? Pn[lane][cc] : ((lane == cc) ? 1.0 : 0.0);
+            } else if (W > s + 1) {
+                // the other tiles of this row block
+#pragma unroll
+                for (int b = s + 2; b <= W; ++b)
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) {
+                        const double bf = Lt[16 * s + 4 * st + lq][16 * b + lr];
+                        T[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[st], bf, T[b], 0, 0, 0);
+                    }
+            }
+        }
     }
     if (W == 3) {
-        // all four barriers have fallen: first non-positive pivot, if any.  A bad pivot makes its column NaN (rsq of a
+        // all barriers have fallen: first non-positive pivot, if any.  A bad pivot makes its column NaN (rsq of a
         // non-positive number, or 0 * inf), and NaN spreads to every later pivot: the first lane whose diagonal entry
         // is not a positive number is the first bad pivot.
         const double d = Lt[lane][lane];
@@ -270,10 +304,11 @@ __device__ __forceinline__ void diag_block_body(double* __restrict__ Abase, int 
                                                 int* __restrict__ info, unsigned long long* __restrict__ stamps,
                                                 double* __restrict__ Lbase, int ldlo, int info_off,
                                                 double* __restrict__ lds) {
-    double (*Lt)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(lds);                       // Lt[k][i] = L[i][k]
-    double (*Tl)[16][17] = reinterpret_cast<double (*)[16][17]>(lds + NB * (NB + 1));       // inverses of the 16x16 diagonal blocks
-    double* rdiag = lds + NB * (NB + 1) + 4 * 16 * 17;                                      // 1 / L[i][i] (inverse-only path)
-    double (*Pn)[17] = reinterpret_cast<double (*)[17]>(lds + NB * (NB + 1));               // panel image (same storage as Tl)
+    lds = static_cast<double*>(__builtin_assume_aligned(lds, 16));
+    double (*Lt)[LTS] = reinterpret_cast<double (*)[LTS]>(lds);                       // Lt[k][i] = L[i][k]
+    double (*Tl)[16][17] = reinterpret_cast<double (*)[16][17]>(lds + NB * LTS);       // inverses of the 16x16 diagonal blocks
+    double* rdiag = lds + NB * LTS + 4 * 16 * 17;                                      // 1 / L[i][i] (inverse-only path)
+    double (*Pn)[17] = reinterpret_cast<double (*)[17]>(lds + NB * LTS);               // panel image (same storage as Tl)
 #define EDRGP_STAMP(slot) do { if (!PRELOADED && stamps != nullptr && threadIdx.x == 0) stamps[slot] = __builtin_amdgcn_s_memtime(); } while (0)
     EDRGP_STAMP(0);
     const int lane = threadIdx.x & 63;

@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256, CAPPED ? 1 : 2) void chol_step_kernel(double* 
     // again), so the next step needs no separate diagonal-block launch on the critical path.
     if (next_diag) {
         lds_barrier();                 // every wave is done with the image of L_i
-        double (*Lt)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(Rbuf);      // Lt[k][i] = block[i][k], identity padded
+        double (*Lt)[LTS] = reinterpret_cast<double (*)[LTS]>(Rbuf);      // Lt[k][i] = block[i][k], identity padded
         const int jb = min(NB, n - (k + 1) * NB);
 #pragma unroll
         for (int x = 0; x < 2; ++x)
