@@ -147,6 +147,10 @@ int fill_pattern(Ctx* c, double* K, size_t n, unsigned long long seed);   // dev
 // upper triangle is zeroed.  *info_dev (device int) receives 0 or the 1-based
 // index of the first non-positive pivot.
 int potrf_lower(Ctx* c, double* A, int n, int lda, int* info_dev);
+// ... the factor left in the library's workspace (*L, ld *ldl; only its lower triangle is meaningful)
+int potrf_lower_ws(Ctx* c, double* A, int n, int lda, int* info_dev, const double** L, int* ldl);
+int aug_setup(Ctx* c, double* Lg, int ldb, const double* A, int n, double shift, const double* v, double scale);
+int aug_tail(Ctx* c, const double* L, int ldl, int n, double* out_logdet, double* out_sumsq);
 // Linv = L^-1 for lower-triangular L (explicit zeros above the diagonal of the output).
 int trtri_lower(Ctx* c, const double* L, int ldl, double* Linv, int ldi, int n);
 // both at once (one launch per 64-column step for n in (64, 3072]: la_chol.hip)
@@ -158,7 +162,6 @@ int potrf_inv_lower_batched(Ctx* c, double* A, int n, int lda, long long strideA
 int gemv_n(Ctx* c, int M, int N, double alpha, const double* A, int lda, const double* x, double* y);
 int gemv_t(Ctx* c, int M, int N, double alpha, const double* A, int lda, const double* x, double* y);
 int add_diag(Ctx* c, double* A, int n, int lda, double v);
-int aug_rhs_row(Ctx* c, double* row, const double* v, int n, double scale);   // row = scale v, row[n] = 1 + |row|^2
 int sum_sq(Ctx* c, const double* x, int64_t n, double* out);               // out[0] = sum x^2
 int dot(Ctx* c, const double* x, const double* y, int64_t n, double* out);
 int trace_of(Ctx* c, const double* A, int n, int lda, double* out);

@@ -420,7 +420,7 @@ __global__ void take_lower_kernel(double* __restrict__ A, int lda, const double*
 // the same launches (see chol_step_kernel).
 static int potrf_lower_fused(Ctx* c, double* A, int n, int lda, int* info_dev, bool reset_info = true,
                              int info_off = 0, double* Linv = nullptr, int ldi = 0, int batch = 1, long long strideA = 0,
-                             long long strideI = 0) {
+                             long long strideI = 0, bool copy_back = true) {
     const size_t G = (size_t)std::max(1, batch);
     if (reset_info) HIP_TRY(hipMemsetAsync(info_dev, 0, G * sizeof(int), c->stream));
     if (c->dinv.bytes < G * 2 * NB * NB * sizeof(double)) {
@@ -489,8 +489,10 @@ static int potrf_lower_fused(Ctx* c, double* A, int n, int lda, int* info_dev, b
         hipLaunchKernelGGL(chol_step_kernel<false>, dim3((unsigned)nblk, (unsigned)G), dim3(256), 0, c->stream, A, lda, Lw, n,
                            Dinv + (size_t)((nblk - 1) & 1) * NB * NB, n, nblk - 1, (double*)nullptr, info_dev, info_off, 0, Cw,
                            n, Linv, ldi, 1, bt, nblk);
-    dim3 blk(64, 4), grd((n + 63) / 64, (n + 3) / 4, (unsigned)G);
-    hipLaunchKernelGGL(take_lower_kernel, grd, blk, 0, c->stream, A, lda, Lw, n, n, bt.sA, bt.sL);
+    if (copy_back) {
+        dim3 blk(64, 4), grd((n + 63) / 64, (n + 3) / 4, (unsigned)G);
+        hipLaunchKernelGGL(take_lower_kernel, grd, blk, 0, c->stream, A, lda, Lw, n, n, bt.sA, bt.sL);
+    }
     HIP_TRY(hipGetLastError());
 #ifdef EDRGP_TILE_STAMPS
     if (stamping) {         // every factorisation overwrites the file: the last one stays
@@ -519,6 +521,22 @@ int potrf_inv_lower(Ctx* c, double* A, int n, int lda, int* info_dev, double* Li
         return potrf_lower_fused(c, A, n, lda, info_dev, true, 0, Linv, ldi);
     TRY(potrf_lower(c, A, n, lda, info_dev));
     return trtri_lower(c, A, lda, Linv, ldi, n);
+}
+
+// Factorisation whose caller only reads the factor: it stays in the workspace it was assembled in (*L, leading
+// dimension *ldl, zeros above the diagonal are NOT guaranteed there) and A holds the updated work matrix; sizes the
+// fused path does not cover are factored in place.
+int potrf_lower_ws(Ctx* c, double* A, int n, int lda, int* info_dev, const double** L, int* ldl) {
+    if (c->chol_fused && n > NB && n <= 3072) {
+        TRY(potrf_lower_fused(c, A, n, lda, info_dev, true, 0, nullptr, 0, 1, 0, 0, false));
+        *L = c->panel.d();
+        *ldl = n;
+        return EDRGP_OK;
+    }
+    TRY(potrf_lower(c, A, n, lda, info_dev));
+    *L = A;
+    *ldl = lda;
+    return EDRGP_OK;
 }
 
 int potrf_lower(Ctx* c, double* A, int n, int lda, int* info_dev) {

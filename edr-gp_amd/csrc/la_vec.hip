@@ -123,27 +123,60 @@ int add_diag(Ctx* c, double* A, int n, int lda, double v) {
 // Right-hand side carried through a Cholesky factorisation as one extra matrix row:
 //   row[j] = scale v[j] (j < n),   row[n] = 1 + sum_j row[j]^2
 // Factoring [[B, .], [row, row[n]]] leaves L^-1 (scale v) in that row; with lambda_min(B) >= 1 the last
-// pivot row[n] - |L^-1 scale v|^2 stays >= 1.  One workgroup, fixed summation order.
-__global__ __launch_bounds__(256) void aug_rhs_row_kernel(double* __restrict__ row, const double* __restrict__ v, int n,
-                                                          double scale) {
-    __shared__ double sh[256];
-    double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const double t = scale * v[i];
-        row[i] = t;
-        s = fma(t, t, s);
-    }
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+// pivot row[n] - |L^-1 scale v|^2 stays >= 1.
+// Set-up of the bound-only factorisation in one launch: Lg (ld ldb, (n+1) x (n+1)) <- [[A + shift I, .], [scale v^T,
+// 1 + |scale v|^2]] from A (n x n, ld n).  Block b copies rows 8 b .. 8 b + 7; the last block writes the extra row.
+__global__ __launch_bounds__(256) void aug_setup_kernel(double* __restrict__ Lg, int ldb, const double* __restrict__ A, int n,
+                                                        double shift, const double* __restrict__ v, double scale) {
+    if ((int)blockIdx.x == (int)gridDim.x - 1) {
+        __shared__ double sh[256];
+        double* row = Lg + (size_t)n * ldb;
+        double s = 0.0;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const double t = scale * v[i];
+            row[i] = t;
+            s = fma(t, t, s);
+        }
+        sh[threadIdx.x] = s;
         __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) row[n] = 1.0 + sh[0];
+        return;
     }
-    if (threadIdx.x == 0) row[n] = 1.0 + sh[0];
+    const int r0 = blockIdx.x * 8;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int r = r0 + u;
+        if (r >= n) break;
+        for (int j = threadIdx.x; j < n; j += 256) Lg[(size_t)r * ldb + j] = A[(size_t)r * n + j] + ((j == r) ? shift : 0.0);
+    }
 }
 
-int aug_rhs_row(Ctx* c, double* row, const double* v, int n, double scale) {
-    hipLaunchKernelGGL(aug_rhs_row_kernel, dim3(1), dim3(256), 0, c->stream, row, v, n, scale);
+int aug_setup(Ctx* c, double* Lg, int ldb, const double* A, int n, double shift, const double* v, double scale) {
+    hipLaunchKernelGGL(aug_setup_kernel, dim3((n + 7) / 8 + 1), dim3(256), 0, c->stream, Lg, ldb, A, n, shift, v, scale);
+    HIP_TRY(hipGetLastError());
+    return EDRGP_OK;
+}
+
+// sum_i log L[i][i] (i < n) and sum_j L[n][j]^2 (j < n) of the factor of that matrix, one launch, fixed order
+__global__ __launch_bounds__(256) void aug_tail_kernel(const double* __restrict__ L, int ldl, int n, double* __restrict__ out_logdet,
+                                                       double* __restrict__ out_sumsq) {
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        s += log(L[(size_t)i * ldl + i]);
+        const double t = L[(size_t)n * ldl + i];
+        q = fma(t, t, q);
+    }
+    s = block_sum256(s);
+    q = block_sum256(q);
+    if (threadIdx.x == 0) { out_logdet[0] = s; out_sumsq[0] = q; }
+}
+
+int aug_tail(Ctx* c, const double* L, int ldl, int n, double* out_logdet, double* out_sumsq) {
+    hipLaunchKernelGGL(aug_tail_kernel, dim3(1), dim3(256), 0, c->stream, L, ldl, n, out_logdet, out_sumsq);
     HIP_TRY(hipGetLastError());
     return EDRGP_OK;
 }

@@ -365,15 +365,15 @@ struct SparseEval {
             const int ldb = M + 8;
             TRY(c->lbaug.reserve((size_t)(M + 1) * ldb * sizeof(double)));
             double* Lg = c->lbaug.d();
-            HIP_TRY(hipMemcpy2DAsync(Lg, (size_t)ldb * sizeof(double), A, (size_t)M * sizeof(double),
-                                     (size_t)M * sizeof(double), (size_t)M, hipMemcpyDeviceToDevice, c->stream));
-            TRY(add_diag(c, Lg, M, ldb, bjit));
-            TRY(aug_rhs_row(c, Lg + (size_t)M * ldb, v_v, M, beta));
-            TRY(potrf_lower(c, Lg, M + 1, ldb, info + 1));
-            TRY(sum_log_diag(c, Lg, M, ldb, sc + SC_SUMLOGLB));
-            TRY(sum_sq(c, Lg + (size_t)M * ldb, M, sc + SC_DATAFIT));
+            // one launch each for the set-up (copy, jitter, right-hand-side row) and for log det / |c|^2, and the factor
+            // is read where the factorisation assembled it (no copy back)
+            TRY(aug_setup(c, Lg, ldb, A, M, bjit, v_v, beta));
+            const double* Lf = nullptr;
+            int ldf = 0;
+            TRY(potrf_lower_ws(c, Lg, M + 1, ldb, info + 1, &Lf, &ldf));
+            TRY(aug_tail(c, Lf, ldf, M, sc + SC_SUMLOGLB, sc + SC_DATAFIT));
             if (f32) {
-                TRY(diag_minmax(c, Lg, M, ldb, sc + SC_LBDIAGMIN));
+                TRY(diag_minmax(c, Lf, M, ldf, sc + SC_LBDIAGMIN));
                 TRY(frob_sq(c, Phi, M, M, sc + SC_PHIFROB));
             }
             return EDRGP_OK;
