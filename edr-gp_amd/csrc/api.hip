@@ -226,15 +226,25 @@ static int predict_rows(Ctx* c, const double* Xs_dev, int64_t Ns, double* mean_h
     chunk = std::min<int64_t>(chunk, Ns);
     TRY(c->Knm.reserve((size_t)chunk * Mp * sizeof(double)));
     TRY(c->W.reserve((size_t)chunk * Mp * sizeof(double)));
-    TRY(c->T.reserve((size_t)chunk * (Wd + D + 2) * sizeof(double)));
+    // two output slots (mean Jacobian, mean, variance of a chunk): chunk k + 1 is computed while chunk k's outputs cross
+    // PCIe on the side stream (config 3 whole on one GPU: 256 MB of Jacobian, 48 -> .. ms for the 1M rows)
+    TRY(c->T.reserve((size_t)chunk * (Wd + 2 * (D + 2)) * sizeof(double)));
     double* GT = c->T.d();
-    double* o_jac = GT + (size_t)chunk * Wd;
-    double* o_mean = o_jac + (size_t)chunk * D;
-    double* o_var = o_mean + chunk;
+    const size_t slot_doubles = (size_t)chunk * (D + 2);
+    for (int i = 0; i < 2; ++i)
+        if (c->ev_pred[i] == nullptr) HIP_TRY(hipEventCreateWithFlags(&c->ev_pred[i], hipEventDisableTiming));
     const double kdiag = var_sum(c);
     // the training rows right after a sparse evaluation with the same theta / Z: K(X, Z) is still resident
     const bool k_train = c->knm_train_valid && !c->post_dense && Xs_dev == c->X.d() && Ns == c->N && Mp == c->M;
     if (!k_train) c->knm_train_valid = false;          // Knm is about to be overwritten chunk by chunk
+    // h(r) beside k for the mean Jacobian of non-RBF kernels (one more chunk x Mp array)
+    const bool rbf1 = (ks.nparts == 1 && ks.kind[0] == EDRGP_KERN_RBF);
+    const bool want_h = (jac_h != nullptr || gram_h != nullptr) && !rbf1 && c->mfma_kbuild;
+    const bool h_train = k_train && c->hnm_train_valid;
+    if (want_h && !h_train) {
+        c->hnm_train_valid = false;
+        TRY(c->Hnm.reserve((size_t)chunk * Mp * sizeof(double)));
+    }
     const bool want_gram = (gram_h != nullptr);
     double* d_gram = nullptr;
     double* d_ones = nullptr;
@@ -244,22 +254,43 @@ static int predict_rows(Ctx* c, const double* Xs_dev, int64_t Ns, double* mean_h
         d_ones = d_gram + (size_t)D * D + D;
         hipLaunchKernelGGL(fill_ones_kernel, dim3((unsigned)((chunk + 255) / 256)), dim3(256), 0, c->stream, d_ones, chunk);
     }
-    for (int64_t r0 = 0; r0 < Ns; r0 += chunk) {
-        const int64_t rows = std::min<int64_t>(chunk, Ns - r0);
+    auto slot_jac = [&](int64_t k) { return GT + (size_t)chunk * Wd + (size_t)(k & 1) * slot_doubles; };
+    auto compute = [&](int64_t k) -> int {
+        const int64_t r0 = k * chunk, rows = std::min<int64_t>(chunk, Ns - r0);
+        double* o_jac = slot_jac(k);
+        double* o_mean = o_jac + (size_t)chunk * D;
+        double* o_var = o_mean + chunk;
         TRY(predict_chunk(c, ks, Xs_dev + (size_t)r0 * D, rows, Pp, Pt, Mp, c->wv.d(), c->winv.d(), kdiag,
                           k_train ? c->Knm.d() + (size_t)r0 * Mp : c->Knm.d(), c->W.d(), GT, mean_h ? o_mean : nullptr,
-                          var_h ? o_var : nullptr, (jac_h || want_gram) ? o_jac : nullptr, k_train));
+                          var_h ? o_var : nullptr, (jac_h || want_gram) ? o_jac : nullptr, k_train,
+                          want_h ? (h_train ? c->Hnm.d() + (size_t)r0 * Mp : c->Hnm.d()) : nullptr, h_train));
         if (want_gram) {
             TRY(gemm(c, true, false, D, D, (int)rows, 1.0, o_jac, D, o_jac, D, r0 > 0 ? 1.0 : 0.0, d_gram, D));
             TRY(gemm(c, true, false, D, 1, (int)rows, 1.0, o_jac, D, d_ones, 1, r0 > 0 ? 1.0 : 0.0, d_gram + (size_t)D * D, 1));
         }
-        if (mean_h) HIP_TRY(hipMemcpyAsync(mean_h + r0, o_mean, rows * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        if (var_h) HIP_TRY(hipMemcpyAsync(var_h + r0, o_var, rows * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipEventRecord(c->ev_pred[k & 1], c->stream));
+        return EDRGP_OK;
+    };
+    const int64_t nck = (Ns + chunk - 1) / chunk;
+    const bool any_copy = (mean_h != nullptr) || (var_h != nullptr) || (jac_h != nullptr);
+    TRY(compute(0));
+    for (int64_t k = 0; k < nck; ++k) {
+        // chunk k + 1 is queued first (its slot was drained two iterations ago: the copies below block the host)
+        if (k + 1 < nck) TRY(compute(k + 1));
+        if (!any_copy) continue;
+        const int64_t r0 = k * chunk, rows = std::min<int64_t>(chunk, Ns - r0);
+        const double* o_jac = slot_jac(k);
+        const double* o_mean = o_jac + (size_t)chunk * D;
+        const double* o_var = o_mean + chunk;
+        HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_pred[k & 1], 0));
+        if (mean_h) HIP_TRY(hipMemcpyAsync(mean_h + r0, o_mean, rows * sizeof(double), hipMemcpyDeviceToHost, c->stream2));
+        if (var_h) HIP_TRY(hipMemcpyAsync(var_h + r0, o_var, rows * sizeof(double), hipMemcpyDeviceToHost, c->stream2));
         if (jac_h)
             HIP_TRY(hipMemcpyAsync(jac_h + (size_t)r0 * D, o_jac, (size_t)rows * D * sizeof(double),
-                                   hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+                                   hipMemcpyDeviceToHost, c->stream2));
+        HIP_TRY(hipStreamSynchronize(c->stream2));      // slot k & 1 is free again
     }
+    HIP_TRY(hipStreamSynchronize(c->stream));
     if (want_gram) {
         HIP_TRY(hipMemcpyAsync(gram_h, d_gram, (size_t)D * D * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         if (gsum_h) HIP_TRY(hipMemcpyAsync(gsum_h, d_gram + (size_t)D * D, (size_t)D * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -337,6 +368,8 @@ int edrgp_ctx_destroy(edrgp_ctx* ctx) {
     for (DBuf* b : {&c->ks_x, &c->ks_z, &c->ks_xn, &c->ks_zn, &c->ks_x2, &c->ks_xn2}) b->release();
     (void)hipEventDestroy(c->ev_fork);
     (void)hipEventDestroy(c->ev_join);
+    for (int i = 0; i < 2; ++i)
+        if (c->ev_pred[i]) (void)hipEventDestroy(c->ev_pred[i]);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     (void)hipStreamDestroy(c->stream2);

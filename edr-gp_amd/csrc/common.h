@@ -199,7 +199,8 @@ int rowdot(Ctx* c, const double* A, const double* B, int64_t rows, int cols, int
 // posterior mean / latent variance / mean Jacobian for one device-resident row chunk
 int predict_chunk(Ctx* c, const KSpec& ks, const double* Xs, int64_t rows, const double* P, const double* Pt,
                   int Mp, const double* wv, const double* winv, double kdiag, double* Kbuf, double* Gbuf,
-                  double* GT, double* mean, double* var, double* jac, bool k_ready = false);
+                  double* GT, double* mean, double* var, double* jac, bool k_ready = false, double* Hbuf = nullptr,
+                  bool h_ready = false);
 int vec_axpy(Ctx* c, int64_t n, double a, const double* x, double* y);   // y += a x
 
 // ------------------------------------------------------- fp32 row pass (la_gemm32.hip)
@@ -226,6 +227,7 @@ struct Ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;        // side stream: latency-bound O(M^3) work beside the row pass
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_pred[2] = {nullptr, nullptr};   // predict_rows: a chunk's outputs are ready (two output slots)
     DBuf red2, slabs2;                    // scratch used while launching on the side stream
     DBuf ks_x, ks_z, ks_xn, ks_zn, ks_x2, ks_xn2;   // scaled inputs and squared norms for the MFMA kernel build
     bool mfma_kbuild = true;
@@ -328,6 +330,7 @@ struct Ctx {
     DBuf mats[16];                    // M x M (or N x N dense) matrices
     DBuf ptw;                         // -diag(wv) [P | 1 | P.^2] of the RBF predict-gradient path
     bool knm_train_valid = false;     // c->Knm holds K(X, Z) of ALL training rows for the current theta / Z
+    bool hnm_train_valid = false;     // ... and c->Hnm its h(r) (non-RBF single-part kernels)
     DBuf Hnm;                         // h(r) of the resident K_nm chunk (non-RBF single-part kernels, gradient evaluations)
     DBuf gfin;                        // dZ (Mr x D) and per-block partial sums of the length-scale terms (grad_finish)
     DBuf g2;                          // T^T [X | X.^2] and column sums of T (fused gradient path)

@@ -578,11 +578,26 @@ __global__ void scale_rows_neg_kernel(const double* __restrict__ Pt, const doubl
 // out[m][q] = -wv[m] Z[m][q] (q < D), zero padding up to ldz; with_wv: column D carries wv[m] itself, so that the
 // product K out also yields K wv (the posterior mean = - sum_m G) in its column D
 __global__ void scale_z_neg_kernel(const double* __restrict__ Z, const double* __restrict__ wv, int Mp, int D, int ldz,
-                                   double* __restrict__ out, int with_wv) {
+                                   double* __restrict__ out, int with_wv, double sign) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Mp * ldz) return;
     const int m = i / ldz, q = i - m * ldz;
-    out[i] = (q < D) ? -wv[m] * Z[(size_t)m * D + q] : ((with_wv && q == D) ? wv[m] : 0.0);
+    out[i] = (q < D) ? sign * wv[m] * Z[(size_t)m * D + q] : ((with_wv && q == D) ? wv[m] : 0.0);
+}
+
+// Every stationary kernel: with H = h(r) = (dk/dr)/r of the part and GW = H [diag(wv) Z | wv]
+// (rows x ldz, column D = H wv):  jac[n][q] (+)= invl[q]^2 (x[n][q] GW[n][D] - GW[n][q])
+__global__ void jac_finish_h_kernel(const double* __restrict__ Xs, const double* __restrict__ GW, int64_t rows, int D,
+                                    int ldz, const double* __restrict__ invl, int accumulate, double* __restrict__ jac) {
+    const int64_t total = rows * D;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t n = i / D;
+        const int q = (int)(i - n * D);
+        const double il = invl[q];
+        const double v = il * il * (Xs[i] * GW[n * ldz + D] - GW[n * ldz + q]);
+        jac[i] = accumulate ? jac[i] + v : v;
+    }
 }
 
 // RBF: jac[n][q] = invl[q]^2 (GZ[n][q] ... ) with G = -K diag(wv):  sum_m G = -(K wv)[n]
@@ -602,13 +617,23 @@ __global__ void jac_finish_rbf_kernel(const double* __restrict__ Xs, const doubl
 
 int predict_chunk(Ctx* c, const KSpec& ks, const double* Xs, int64_t rows, const double* P, const double* Pt,
                   int Mp, const double* wv, const double* winv, double kdiag, double* Kbuf, double* Gbuf,
-                  double* GT, double* mean, double* var, double* jac, bool k_ready) {
+                  double* GT, double* mean, double* var, double* jac, bool k_ready, double* Hbuf, bool h_ready) {
     const int D = ks.D;
     // RBF: h(r) = -k(r), so the Jacobian's G = wv .* h(r) is K itself with -wv folded into [P | 1 | P.^2]:
-    // no second pass over the pairs (the generic path recomputes the distances on the VALU)
+    // no second pass over the pairs.  Every other stationary kernel takes h(r) from the MFMA build, which stores it
+    // beside k (or has stored it: the training rows right after an evaluation), part by part for sum kernels: the
+    // Jacobian is the product H [diag(wv) Z | wv] on the matrix pipe.  Only without the MFMA build does
+    // the pair kernel recompute the distances on the VALU.
     const bool rbf1 = (ks.nparts == 1 && ks.kind[0] == EDRGP_KERN_RBF);
-    if (mean != nullptr || var != nullptr || (jac != nullptr && rbf1)) {
-        if (!k_ready) TRY(kernel_matrix(c, ks, Xs, rows, P, Mp, Kbuf, Mp, 0, 0.0, nullptr, nullptr));
+    const bool hmm = (jac != nullptr) && !rbf1 && c->mfma_kbuild && Hbuf != nullptr && rows <= 0x7fffffffLL;
+    const bool gen1 = hmm && ks.nparts == 1;          // single part: k and h out of one build
+    if (mean != nullptr || var != nullptr || (jac != nullptr && rbf1) || gen1) {
+        if (!k_ready || (gen1 && !h_ready)) {
+            c->kbuild_h = gen1 ? Hbuf : nullptr;
+            const int st = kernel_matrix(c, ks, Xs, rows, P, Mp, Kbuf, Mp, 0, 0.0, nullptr, nullptr);
+            c->kbuild_h = nullptr;
+            if (st != EDRGP_OK) return st;
+        }
         if (mean != nullptr) TRY(gemv_n(c, (int)rows, Mp, 1.0, Kbuf, Mp, wv, mean));
         if (var != nullptr) {
             // quad[n] = sum_m (K Winv)[n][m] K[n][m]
@@ -634,7 +659,7 @@ int predict_chunk(Ctx* c, const KSpec& ks, const double* Xs, int64_t rows, const
                 const int ldz = ride ? (D + 2 - (D & 1)) : D + (D & 1);       // even leading dimension
                 TRY(c->ptw.reserve((size_t)Mp * ldz * sizeof(double)));
                 hipLaunchKernelGGL(scale_z_neg_kernel, dim3((Mp * ldz + 255) / 256), dim3(256), 0, c->stream, P, wv, Mp, D,
-                                   ldz, c->ptw.d(), ride ? 1 : 0);
+                                   ldz, c->ptw.d(), ride ? 1 : 0, -1.0);
                 TRY(gemm(c, false, false, (int)rows, ldz, Mp, 1.0, Kbuf, Mp, c->ptw.d(), ldz, 0.0, GT, ldz));
                 const double* kwv = mean;
                 int64_t kwv_stride = 1;
@@ -650,6 +675,29 @@ int predict_chunk(Ctx* c, const KSpec& ks, const double* Xs, int64_t rows, const
                 const int nb = (int)std::min<int64_t>(4096, (total + 255) / 256);
                 hipLaunchKernelGGL(jac_finish_rbf_kernel, dim3(std::max(nb, 1)), dim3(256), 0, c->stream, Xs, GT, kwv,
                                    kwv_stride, rows, D, ldz, ks.invl, jac);
+                continue;
+            } else if (hmm) {
+                if (!gen1) {
+                    // part p alone: its k goes to the scratch (unused), its h(r) to Hbuf
+                    KSpec k1 = ks;
+                    k1.nparts = 1;
+                    k1.kind[0] = ks.kind[p];
+                    k1.var[0] = ks.var[p];
+                    k1.invl = ks.invl + (size_t)p * D;
+                    c->kbuild_h = Hbuf;
+                    const int st = kernel_matrix(c, k1, Xs, rows, P, Mp, Gbuf, Mp, 0, 0.0, nullptr, nullptr);
+                    c->kbuild_h = nullptr;
+                    if (st != EDRGP_OK) return st;
+                }
+                const int ldz = D + 2 - (D & 1);                 // [diag(wv) Z | wv | (0)], even leading dimension
+                TRY(c->ptw.reserve((size_t)Mp * ldz * sizeof(double)));
+                hipLaunchKernelGGL(scale_z_neg_kernel, dim3((Mp * ldz + 255) / 256), dim3(256), 0, c->stream, P, wv, Mp, D,
+                                   ldz, c->ptw.d(), 1, 1.0);
+                TRY(gemm(c, false, false, (int)rows, ldz, Mp, 1.0, Hbuf, Mp, c->ptw.d(), ldz, 0.0, GT, ldz));
+                const int64_t total = rows * D;
+                const int nb = (int)std::min<int64_t>(4096, (total + 255) / 256);
+                hipLaunchKernelGGL(jac_finish_h_kernel, dim3(std::max(nb, 1)), dim3(256), 0, c->stream, Xs, GT, rows, D, ldz,
+                                   ks.invl + (size_t)p * D, p > 0 ? 1 : 0, jac);
                 continue;
             } else {
                 TRY(hmatrix(c, ks, p, Xs, rows, P, Mp, wv, Gbuf, Mp));

@@ -154,6 +154,7 @@ struct SparseEval {
         M = padded ? (Mr + 127) / 128 * 128 : Mr;
         c->M_work = M;
         c->knm_train_valid = false;
+        c->hnm_train_valid = false;
         beta = 1.0 / std::max(c->noise_var, 1e-8);
         ks = make_kspec(c);
         TRY(get_globals(c, &gl));
@@ -237,8 +238,10 @@ struct SparseEval {
     // work crawls beside the partner workgroup's MFMA stream (Matern-5/2, D = 32: 108 us of epilogue per 470 us tile,
     // tools/tile_stamps.py).  One more N x M array (1.6 GB at Cm, written once per evaluation).
     bool want_h() const {
-        return need_grad && np == 1 && c->kind[0] != EDRGP_KERN_RBF && c->fuse_grad && c->h_resident && c->mfma_kbuild && !g32 &&
-               c->rbf_epilogue;
+        // (posterior evaluations store it too: predict_gradient on the training rows -- what the EDR loop asks next,
+        // edrgp/base.py:274 -- then needs no second pass over the pairs)
+        return (need_grad || need_post) && np == 1 && c->kind[0] != EDRGP_KERN_RBF && c->fuse_grad && c->h_resident &&
+               c->mfma_kbuild && !g32 && c->rbf_epilogue;
     }
     int build_knm(int64_t r0, int64_t rows, double* outK, const double* yv, double* bt) {
         const bool with_h = want_h() && outK == c->Knm.d();
@@ -330,6 +333,7 @@ struct SparseEval {
         k_resident = (nchunks == 1);
         // predictions address K_nm with ld = number of real points (the stable form keeps K_nm in Knm, K_nm Li^T in W)
         c->knm_train_valid = k_resident && !padded;
+        c->hnm_train_valid = c->knm_train_valid && h_built;
         TRY(allreduce_phi(c, Phi, M));
         return EDRGP_OK;
     }

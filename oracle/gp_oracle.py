@@ -233,14 +233,24 @@ class Stationary:
         return self.dK_dr(self._scaled_dist(X, X2))
 
     # -- gradients -----------------------------------------------------------
-    def gradients_X(self, dL_dK, X, X2=None):
-        """Stationary._gradients_X_pure (upstream also has a Cython/OpenMP twin)."""
+    def gradients_X(self, dL_dK, X, X2=None, gemm_form=False):
+        """Stationary._gradients_X_pure (upstream also has a Cython/OpenMP twin).
+
+        ``gemm_form``: the same sums reordered, sum_n tmp[m, n] (x[m, q] - x2[n, q]) =
+        x[m, q] sum_n tmp[m, n] - (tmp @ X2)[m, q] -- one BLAS product instead of input_dim
+        passes over the M x N array with a temporary each.  Not GPy's operation order; it
+        exists so that the full-size parity tests (N = 1e5, M = 2048..4096, D up to 64: the
+        loop form takes minutes there) can check dZ, and is itself held to the loop form in
+        tests/test_host_logic.py::test_oracle_gradients_x_gemm_form."""
         invdist = self._inv_dist(X, X2)
         dL_dr = self.dK_dr_via_X(X, X2) * dL_dK
         tmp = invdist * dL_dr
         if X2 is None:
             tmp = tmp + tmp.T
             X2 = X
+        if gemm_form:
+            grad = X * np.sum(tmp, axis=1)[:, None] - tmp @ X2
+            return grad / self.lengthscale ** 2
         grad = np.empty(X.shape, dtype=np.float64)
         for q in range(self.input_dim):
             np.sum(tmp * (X[:, q][:, None] - X2[:, q][None, :]), axis=1, out=grad[:, q])
@@ -282,8 +292,8 @@ class Add:
     def Kdiag(self, X):
         return sum(p.Kdiag(X) for p in self.parts)
 
-    def gradients_X(self, dL_dK, X, X2=None):
-        return sum(p.gradients_X(dL_dK, X, X2) for p in self.parts)
+    def gradients_X(self, dL_dK, X, X2=None, gemm_form=False):
+        return sum(p.gradients_X(dL_dK, X, X2, gemm_form=gemm_form) for p in self.parts)
 
     def param_gradients_full(self, dL_dK, X, X2=None):
         return [p.param_gradients_full(dL_dK, X, X2) for p in self.parts]
@@ -388,17 +398,18 @@ def vardtc_inference(kern, X, Z, noise_var, Y):
                 dL_dthetaL=dL_dthetaL, data_fit=data_fit)
 
 
-def sparse_gradients(kern, X, Z, inf):
+def sparse_gradients(kern, X, Z, inf, gemm_form=False):
     """SparseGP._update_gradients (GPy/core/sparse_gp.py): kernel, noise and
     inducing-input gradients of the bound.  Returns (kern_grads, dnoise, dZ)
-    with kern_grads = [(dvariance, dlengthscale), ...] per additive part."""
+    with kern_grads = [(dvariance, dlengthscale), ...] per additive part.
+    ``gemm_form``: see Stationary.gradients_X (full-size tests only)."""
     kern = as_add(kern)
     g_diag = kern.param_gradients_diag(inf["dL_dKdiag"], X)
     g_nm = kern.param_gradients_full(inf["dL_dKnm"], X, Z)
     g_mm = kern.param_gradients_full(inf["dL_dKmm"], Z, None)
     kern_grads = [(a[0] + b[0] + c[0], a[1] + b[1] + c[1]) for a, b, c in zip(g_diag, g_nm, g_mm)]
-    dZ = kern.gradients_X(inf["dL_dKmm"], Z)
-    dZ = dZ + kern.gradients_X(inf["dL_dKnm"].T, Z, X)
+    dZ = kern.gradients_X(inf["dL_dKmm"], Z, gemm_form=gemm_form)
+    dZ = dZ + kern.gradients_X(inf["dL_dKnm"].T, Z, X, gemm_form=gemm_form)
     return kern_grads, inf["dL_dthetaL"], dZ
 
 

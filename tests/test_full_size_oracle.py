@@ -1,10 +1,15 @@
 """Parity with the CPU oracle AT BASELINE.json's full sizes (SURVEY 8d gate: bound <= 1e-10 rel, posterior mean
 on the N training rows <= 1e-8 rel), through the C ABI, in the library's default (automatic) statistics mode:
-  Cm  N = 100 000, M = 2048, D = 32, RBF  (the metric's configuration; Gram form)
-  C2  N = 100 000, M = 1024, D = 16, RBF  (stable form: its Kmm is the worse conditioned one)
+  Cm   N = 100 000, M = 2048, D = 32, RBF        (the metric's configuration; Gram form)
+  C2   N = 100 000, M = 1024, D = 16, RBF        (stable form: its Kmm is the worse conditioned one)
+  C3s  N = 125 000, M = 2048, D = 32, Matern-5/2 (one GPU's shard of config 3)
+  C5c  N = 131 072, M = 4096, D = 64, RBF        (one row chunk of config 5), `precision` 64 and 32
 One oracle inference per configuration (GPy's operation sequence in numpy/scipy on the host cores: tens of
-seconds) + the oracle's posterior mean / variance on the N rows; C2 adds a directional derivative of the ORACLE's
-bound along a random direction of Z (two more oracle inferences) against the device's analytic dZ.
+seconds), the oracle's posterior mean / variance on the rows, and the oracle's gradients of the bound
+(SparseGP._update_gradients: d/dvariance, d/dlengthscale, d/dnoise, dZ; the inducing-input gradient in the
+oracle's reordered form -- one BLAS product instead of D passes over the N x M array, itself held to GPy's loop form in
+tests/test_host_logic.py::test_oracle_gradients_x_gemm_form).  C2 adds a directional derivative of the ORACLE's bound
+along a random direction of Z (two more oracle inferences) against the device's analytic dZ.
 Inputs follow SURVEY 8(d): Z = X[perm[:M]].  Run last (module name sorts after test_full_size.py)."""
 import time
 
@@ -37,22 +42,57 @@ class _host_cores:
         return False
 
 
-@pytest.mark.parametrize("name,N,M,D,fd_on_oracle", [("Cm", 100000, 2048, 32, False), ("C2", 100000, 1024, 16, True)])
-def test_full_size_against_oracle(hip, name, N, M, D, fd_on_oracle):
-    X, y, Z = synthetic(N, D, M, seed=0)
-    ell, noise = float(np.sqrt(D)), 0.01
-    kern = go.make_kernel(["RBF"], D, [dict(variance=1.0, lengthscale=ell)])
+def rel(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def device_run(hip, X, y, Z, kind, ell, noise, precision, n_var):
+    D = X.shape[1]
     hip.set_option("stats_mode", 0)
     hip.set_option("chunk_rows", 131072)
+    hip.set_option("precision", precision)
     hip.set_data(X, y)
     hip.set_inducing(Z)
-    hip.set_kernel(["RBF"], [1.0], np.full((1, D), ell), noise)
-    lml_only = hip.sparse_lml()
-    lml, dvar, dlen, dnoise, dZ = hip.sparse_lml_grad()
-    mode = int(hip.get("MODE", (1,))[0])
-    lml_post = hip.sparse_posterior()
-    mu, _ = hip.predict_train(want_mean=True, want_grad=False)
-    mu_p, var_p = hip.predict(X[:4096])
+    hip.set_kernel([kind], [1.0], np.full((1, D), ell), noise)
+    out = {"lml_only": hip.sparse_lml()}
+    out["lml"], out["dvar"], out["dlen"], out["dnoise"], out["dZ"] = hip.sparse_lml_grad()
+    out["mode"] = int(hip.get("MODE", (1,))[0])
+    out["lml_post"] = hip.sparse_posterior()
+    out["mu"], _ = hip.predict_train(want_mean=True, want_grad=False)
+    out["mu_p"], out["var_p"] = hip.predict(X[:n_var])
+    out["wv"] = hip.get("WV", (Z.shape[0],))
+    return out
+
+
+# name, N, M, D, kernel, precisions, directional derivative of the oracle's bound along Z, gate (bound, posterior mean)
+# The fp64 BASELINE configurations are held to SURVEY 8(d)'s gate, 1e-10 / 1e-8.  The chunk of config 5 -- BASELINE's
+# fp32 configuration, for which SURVEY asks for "the achieved tolerance" -- lands at 1.1e-10 / 2.1e-8 in fp64 and is
+# gated at 3e-10 / 5e-8: its two statistics forms agree with each other to 7e-12 / 1.2e-8 (tools/cond_probe.py) and the
+# oracle moves by 3e-15 / 5e-13 when the last bit of its inputs is perturbed (tools/oracle_floor.py), so the difference
+# is the device's own and common to both forms -- the explicit Lm^-1 (cond(Lm) ~ 1e4 at M = 4096) where GPy solves
+# with the triangular factor.
+CONFIGS = [
+    ("Cm", 100000, 2048, 32, "RBF", (64,), False, (1e-10, 1e-8)),
+    ("C2", 100000, 1024, 16, "RBF", (64,), True, (1e-10, 1e-8)),
+    ("C3s", 125000, 2048, 32, "Matern52", (64,), False, (1e-10, 1e-8)),
+    ("C5c", 131072, 4096, 64, "RBF", (64, 32), False, (3e-10, 5e-8)),
+]
+# precision 32: Phi comes from the fp64 row pass (the bound is the fp64 one); K_nm and the gradient contraction are
+# fp32 -- DESIGN section 6 states 6e-3 / 4e-3 / 2.7e-2 for d/dvariance, d/dlengthscale, dZ at config 5
+TOL = {64: dict(dvar=1e-7, dlen=1e-7, dnoise=1e-7, dZ=1e-6), 32: dict(dvar=2e-2, dlen=2e-2, dnoise=1e-7, dZ=6e-2)}
+
+
+@pytest.mark.parametrize("name,N,M,D,kind,precisions,fd_on_oracle,gate", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_full_size_against_oracle(hip, name, N, M, D, kind, precisions, fd_on_oracle, gate):
+    X, y, Z = synthetic(N, D, M, seed=0)
+    ell, noise = float(np.sqrt(D)), 0.01
+    kern = go.make_kernel([kind], D, [dict(variance=1.0, lengthscale=ell)])
+    n_var = 4096
+    try:
+        dev = {p: device_run(hip, X, y, Z, kind, ell, noise, p, n_var) for p in precisions}
+    finally:
+        hip.set_option("precision", 64)
 
     with _host_cores():
         t0 = time.perf_counter()
@@ -61,35 +101,42 @@ def test_full_size_against_oracle(hip, name, N, M, D, fd_on_oracle):
         ref = float(inf["log_marginal"][0, 0])
         wv = inf["woodbury_vector"]
         mu_ref = (inf["psi1"] @ wv)[:, 0]                  # Posterior._raw_predict mean: K(X*, Z) woodbury_vector
-        mu4, var4 = go.raw_predict(kern, X[:4096], Z, wv, inf["woodbury_inv"])
-        print("\n[%s] oracle inference %.1f s; bound %.9f (device %.9f, mode %d); rel err bound %.2e / %.2e / %.2e, "
-              "mean %.2e, var %.2e" % (name, t_inf, ref, lml, mode, abs(lml - ref) / abs(ref), abs(lml_only - ref) / abs(ref),
-                                       abs(lml_post - ref) / abs(ref), np.abs(mu - mu_ref).max() / np.abs(mu_ref).max(),
-                                       np.abs(var_p - var4[:, 0]).max()))
-        # SURVEY 8(d) gate
-        for v in (lml, lml_only, lml_post):
-            assert abs(v - ref) <= 1e-10 * abs(ref), (v, ref)
-        assert np.abs(mu - mu_ref).max() <= 1e-8 * np.abs(mu_ref).max()
-        assert np.abs(mu_p - mu4[:, 0]).max() <= 1e-8 * np.abs(mu_ref).max()
-        assert np.abs(var_p - var4[:, 0]).max() <= 1e-7
-        assert np.abs(hip.get("WV", (M,)) - wv[:, 0]).max() <= 1e-6 * np.abs(wv).max()
-        # dL/dnoise and dL/dvariance need no further pass over the rows in the oracle either
-        kdiag_term = float(np.sum(inf["dL_dKdiag"]))       # d/dvariance part of Kdiag; full check of dvar below is FD
-        assert np.isfinite(kdiag_term)
-        assert abs(dnoise - inf["dL_dthetaL"]) <= 1e-7 * abs(inf["dL_dthetaL"])
-        del inf
+        mu4, var4 = go.raw_predict(kern, X[:n_var], Z, wv, inf["woodbury_inv"])
+        t0 = time.perf_counter()
+        kg, dn_ref, dZ_ref = go.sparse_gradients(kern, X, Z, inf, gemm_form=True)
+        t_grad = time.perf_counter() - t0
+        dvar_ref, dlen_ref = float(kg[0][0]), float(np.sum(kg[0][1]))
+        for p in precisions:
+            d = dev[p]
+            print("\n[%s, precision %d] oracle inference %.1f s + gradients %.1f s; bound %.9f (device %.9f, mode %d); rel err bound "
+                  "%.2e / %.2e / %.2e, mean %.2e, var %.2e, dvar %.2e, dlen %.2e, dnoise %.2e, dZ %.2e"
+                  % (name, p, t_inf, t_grad, ref, d["lml"], d["mode"], abs(d["lml"] - ref) / abs(ref),
+                     abs(d["lml_only"] - ref) / abs(ref), abs(d["lml_post"] - ref) / abs(ref), rel(d["mu"], mu_ref),
+                     np.abs(d["var_p"] - var4[:, 0]).max(), abs(d["dvar"][0] - dvar_ref) / abs(dvar_ref),
+                     abs(d["dlen"][0].sum() - dlen_ref) / abs(dlen_ref), abs(d["dnoise"] - dn_ref) / abs(dn_ref),
+                     rel(d["dZ"], dZ_ref)))
+            # SURVEY 8(d) gate (the fp32 row pass keeps the fp64 bound and posterior)
+            for v in (d["lml"], d["lml_only"], d["lml_post"]):
+                assert abs(v - ref) <= gate[0] * abs(ref), (p, v, ref)
+            assert rel(d["mu"], mu_ref) <= gate[1]
+            assert np.abs(d["mu_p"] - mu4[:, 0]).max() <= gate[1] * np.abs(mu_ref).max()
+            assert np.abs(d["var_p"] - var4[:, 0]).max() <= 1e-7
+            assert np.abs(d["wv"] - wv[:, 0]).max() <= 1e-6 * np.abs(wv).max()
+            # gradients of the bound against SparseGP._update_gradients
+            tol = TOL[p]
+            assert abs(d["dvar"][0] - dvar_ref) <= tol["dvar"] * abs(dvar_ref), (p, d["dvar"], dvar_ref)
+            assert abs(d["dlen"][0].sum() - dlen_ref) <= tol["dlen"] * abs(dlen_ref), (p, d["dlen"][0].sum(), dlen_ref)
+            assert abs(d["dnoise"] - dn_ref) <= tol["dnoise"] * abs(dn_ref), (p, d["dnoise"], dn_ref)
+            assert rel(d["dZ"], dZ_ref) <= tol["dZ"], (p, rel(d["dZ"], dZ_ref))
+        del inf, kg, dZ_ref
 
-        V = np.random.default_rng(5).standard_normal(Z.shape)
-        an = float(np.sum(dZ * V))
-        t = 1e-4
         if fd_on_oracle:
+            d = dev[64]
+            V = np.random.default_rng(5).standard_normal(Z.shape)
+            an = float(np.sum(d["dZ"] * V))
+            t = 1e-4
             up = go.vardtc_inference(kern, X, Z + t * V, noise, y[:, None])["log_marginal"][0, 0]
             dn = go.vardtc_inference(kern, X, Z - t * V, noise, y[:, None])["log_marginal"][0, 0]
             fd = float(up - dn) / (2 * t)
-        else:
-            def bound(Zz):
-                hip.set_inducing(Zz)
-                return hip.sparse_lml()
-            fd = (bound(Z + t * V) - bound(Z - t * V)) / (2 * t)
-        print("[%s] dZ . V analytic %.6e, central difference of the %s bound %.6e" % (name, an, "oracle's" if fd_on_oracle else "device", fd))
-        assert abs(fd - an) <= 1e-3 * abs(an), (fd, an)
+            print("[%s] dZ . V analytic %.6e, central difference of the oracle's bound %.6e" % (name, an, fd))
+            assert abs(fd - an) <= 1e-3 * abs(an), (fd, an)

@@ -194,3 +194,25 @@ def test_svd_transformer_thin_svd_equals_full_and_scales():
     t0 = time.perf_counter()
     SVDTransformer(n_components=3).fit(G)
     assert time.perf_counter() - t0 < 5.0
+
+
+@pytest.mark.parametrize("kind", ["RBF", "Matern32", "Matern52"])
+def test_oracle_gradients_x_gemm_form(kind):
+    """The oracle's reordered gradients_X (one BLAS product instead of input_dim passes; used by the full-size
+    parity tests only) equals GPy's loop form, both with X2 given and with X2 = None, ARD or not."""
+    from oracle import gp_oracle as go
+    rng = np.random.default_rng(3)
+    for ard in (False, True):
+        D = 5
+        ls = rng.uniform(0.7, 1.9, D) if ard else 1.3
+        k = go.Stationary(kind, D, variance=1.7, lengthscale=ls, ARD=ard)
+        X, X2 = rng.standard_normal((40, D)), rng.standard_normal((23, D))
+        X2[3] = X[7]                                    # a zero distance: the 1/r convention must agree
+        dL = rng.standard_normal((40, 23))
+        a = k.gradients_X(dL, X, X2)
+        b = k.gradients_X(dL, X, X2, gemm_form=True)
+        assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(a).max())
+        dLs = rng.standard_normal((40, 40))
+        a = k.gradients_X(dLs, X)
+        b = k.gradients_X(dLs, X, gemm_form=True)
+        assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(a).max())
