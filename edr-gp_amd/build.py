@@ -25,8 +25,10 @@ if VARIANT:
     OBJ = os.path.join(HERE, "csrc", "_obj_" + VARIANT)
     LIB = os.path.join(HERE, "libedrgp_hip_%s.so" % VARIANT)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# every variant build is a PROBE build: it alone knows the A/B switches, launch-geometry knobs and wrong-result timing
+# probes behind edrgp_set_option (csrc/api.hip) and links the pattern microbenchmarks of csrc/calib.hip
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result",
-         "-I/opt/rocm/include"] + ({"stamps": ["-DEDRGP_TILE_STAMPS"]}.get(VARIANT, []) if VARIANT else []) + \
+         "-I/opt/rocm/include"] + (["-DEDRGP_PROBE_BUILD"] + {"stamps": ["-DEDRGP_TILE_STAMPS"]}.get(VARIANT, []) if VARIANT else []) + \
         os.environ.get("EDRGP_VARIANT_FLAGS", "").split()
 
 

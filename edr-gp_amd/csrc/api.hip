@@ -395,12 +395,32 @@ int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
     CTX(ctx);
     ++c->state_serial;
     if (!key) return EDRGP_ERR_INVALID;
+    // The product's options (include/edrgp_hip.h documents each).  None of them changes WHAT is computed beyond the
+    // documented numerical choices (statistics form, precision of the row pass).
     if (!std::strcmp(key, "chunk_rows")) c->chunk_rows = std::max<int64_t>(64, (int64_t)value);
-    else if (!std::strcmp(key, "syrk_splits")) c->syrk_splits = (int)value;
-    else if (!std::strcmp(key, "profile")) c->profile = (value != 0.0);
     else if (!std::strcmp(key, "stats_mode")) c->stats_mode = (int)value;          // 0 auto, 1 gram, 2 stable
     else if (!std::strcmp(key, "pivot_ratio_max")) c->pivot_ratio_max = value;
     else if (!std::strcmp(key, "overlap")) c->overlap = (int)value;
+    else if (!std::strcmp(key, "sync_free")) c->sync_free = (value != 0.0);
+    else if (!std::strcmp(key, "posterior_reuse")) c->posterior_reuse = (value != 0.0);
+    else if (!std::strcmp(key, "pad_inducing")) c->pad_inducing = (value != 0.0);
+    else if (!std::strcmp(key, "profile")) c->profile = (value != 0.0);
+    else if (!std::strcmp(key, "f32_ratio_max")) c->f32_ratio_max = value;
+    else if (!std::strcmp(key, "f32_guard")) c->f32_guard = value;
+    else if (!std::strcmp(key, "f32_phi")) { c->f32_phi = (value != 0.0); c->phi32_bad = false; }
+    else if (!std::strcmp(key, "precision")) {
+        // 64 (default): fp64 throughout.  32: the N-proportional row pass in fp32 (la_gemm32.hip)
+        if ((int)value != 32 && (int)value != 64) { set_error("precision must be 32 or 64"); return EDRGP_ERR_INVALID; }
+        c->precision = (int)value;
+        c->have_post = false;
+        c->last_mode = 0;
+        c->phi32_bad = false;
+    }
+#ifdef EDRGP_PROBE_BUILD
+    // Probe builds only (EDRGP_BUILD_VARIANT=<name> python edr-gp_amd/build.py -> libedrgp_hip_<name>.so, tools/):
+    // A/B switches of settled design decisions, launch-geometry knobs, and timing probes whose results are wrong
+    // (gemm_alias, kbuild_dbg, dbg_gemm_*).  The product library does not know these keys.
+    else if (!std::strcmp(key, "syrk_splits")) c->syrk_splits = (int)value;
     else if (!std::strcmp(key, "trace")) c->trace = (value != 0.0);
     else if (!std::strcmp(key, "gemm_dephase")) c->gemm_dephase = (int)value;
     else if (!std::strcmp(key, "gemm_alias")) c->gemm_alias = (int)value;
@@ -429,24 +449,11 @@ int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
     else if (!std::strcmp(key, "chol_cap_grid")) c->chol_cap_grid = (value != 0.0);
     else if (!std::strcmp(key, "chol_inv_fused")) c->chol_inv_fused = (value != 0.0);
     else if (!std::strcmp(key, "chol_rhs")) c->chol_rhs = (value != 0.0);
-    else if (!std::strcmp(key, "pad_inducing")) c->pad_inducing = (value != 0.0);
     else if (!std::strcmp(key, "gemm_pair")) c->gemm_pair = (value != 0.0);
-    else if (!std::strcmp(key, "posterior_reuse")) c->posterior_reuse = (value != 0.0);
     else if (!std::strcmp(key, "prebuild")) c->prebuild = (value != 0.0);
     else if (!std::strcmp(key, "syrk_xmap")) c->syrk_xmap = (value != 0.0);
     else if (!std::strcmp(key, "syrk_diag_opt")) c->syrk_diag_opt = (value != 0.0);
-    else if (!std::strcmp(key, "sync_free")) c->sync_free = (value != 0.0);
-    else if (!std::strcmp(key, "f32_ratio_max")) c->f32_ratio_max = value;
-    else if (!std::strcmp(key, "f32_guard")) c->f32_guard = value;
-    else if (!std::strcmp(key, "f32_phi")) { c->f32_phi = (value != 0.0); c->phi32_bad = false; }
-    else if (!std::strcmp(key, "precision")) {
-        // 64 (default): fp64 throughout.  32: the N-proportional row pass in fp32 (la_gemm32.hip)
-        if ((int)value != 32 && (int)value != 64) { set_error("precision must be 32 or 64"); return EDRGP_ERR_INVALID; }
-        c->precision = (int)value;
-        c->have_post = false;
-        c->last_mode = 0;
-        c->phi32_bad = false;
-    }
+#endif
     else { set_error("unknown option %s", key); return EDRGP_ERR_INVALID; }
     return EDRGP_OK;
 }
@@ -1039,6 +1046,7 @@ int edrgp_dbg_mfma_layout(edrgp_ctx* ctx, const double* A16x4, const double* B4x
 
 int edrgp_calib(edrgp_ctx* ctx, double* mfma_f64_tflops, double* hbm_copy_gbps) {
     CTX(ctx);
+#ifdef EDRGP_PROBE_BUILD
     if (getenv("EDRGP_CALIB_PATTERNS")) {
         double t[10] = {0};
         TRY(calib_mfma_patterns(c, t));
@@ -1058,6 +1066,7 @@ int edrgp_calib(edrgp_ctx* ctx, double* mfma_f64_tflops, double* hbm_copy_gbps) 
                     t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10], t[11]);
         }
     }
+#endif
     if (mfma_f64_tflops) TRY(calib_mfma_f64(c, mfma_f64_tflops));
     if (hbm_copy_gbps) TRY(calib_hbm_copy(c, hbm_copy_gbps));
     return EDRGP_OK;

@@ -36,6 +36,8 @@ __global__ __launch_bounds__(256) void mfma_f64_rate_kernel(int iters, double* s
 // (consecutive instructions share neither operand)
 // The loop skeleton (F = 15) with the fragments of k-step s+1 read during the MFMAs of step s (register
 // double-buffered fragments, +16 VGPRs); WR = k-step after which the staging stores are issued.
+#ifdef EDRGP_PROBE_BUILD
+// ---- loop-skeleton and issue-order microbenchmarks (probe builds only: DESIGN section 5 cites their numbers)
 template <int WR>
 __global__ __launch_bounds__(256, 2) void mfma_prefetch_kernel(int iters, double* sink, const double* __restrict__ gsrc,
                                                               long long gstride) {
@@ -325,6 +327,8 @@ int calib_mfma_orders(Ctx* c, double* t) {
     g.release();
     return EDRGP_OK;
 }
+
+#endif  // EDRGP_PROBE_BUILD
 
 int calib_mfma_f64(Ctx* c, double* tflops) {
     TRY(c->red.reserve(64));

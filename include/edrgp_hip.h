@@ -82,41 +82,33 @@ int  edrgp_device_count(int* count);
 int  edrgp_ctx_create(int device, edrgp_ctx** ctx);
 int  edrgp_ctx_destroy(edrgp_ctx* ctx);
 int  edrgp_sync(edrgp_ctx* ctx);
-/* tunables: "chunk_rows", "syrk_splits", "profile" (0/1), "stats_mode" (0 auto,
- * 1 Gram form Phi = K_mn K_nm, 2 stable form via K_nm Lm^-T), "pivot_ratio_max",
- * "overlap" (side-stream use: 0 none, 1 the Kmm gradient term beside the gradient contraction and
- * the K_nm build beside the Kmm factorisation, 2 the whole row pass beside the Kmm factorisation,
- * 3 (default) = 1, and 2 only for bound-only evaluations whose row pass is chunked), "precision" (64 default; 32 = BASELINE config 5: K_nm stored in fp32 and the
- * gradient contraction T = (K_nm S2 + ..) .* h(r), T^T [X | X.^2] on the fp32 MFMA with fp64 slab sums,
- * for single-part kernels with D <= 64 while Kmm is conditioned for the Gram form; the bound itself stays
- * fp64.  "f32_phi" = 1 additionally tries the Gram matrix Phi in fp32 and keeps it only if the
- * factorisation of I + A succeeds without jitter and an error estimate stays below "f32_guard"
- * (EDRGP_GET_MODE reports 3 then; the bound is 1e-4..1e-3 accurate in that mode)).
- * A/B switches of individual optimisations, all on by default and result-neutral: "fuse_grad",
- * "rbf_epilogue", "syrk_xmap", "syrk_diag_opt", "chol_fused",
- * "chol_rhs" (bound-only: right-hand side carried through the second factorisation, no explicit inverse),
- * "pad_inducing" (M > 256 not a multiple of 128: decoupled phantom inducing points up to the next multiple),
- * "gemm_pair" (stable form's K_nm Lm^-T: column tiles paired long + short per workgroup),
- * "posterior_reuse" (edrgp_sparse_posterior right after a bound+gradient evaluation of the same state is
- *  served from that evaluation's factors),
- * "mfma_kbuild", "kbuild_tile" (64 / 128),
- * "gemm_dephase", "tri_tile",
- * "gemm_persist" (0 off, 1 the gradient contraction, 2 also the stable form's product run as persistent grids of two
- *  workgroups per CU), "syrk_persist" (the Phi launch likewise where it has the GPU to itself),
- * "kmm_early" (Kmm-term products that need A only run beside the factorisation of I + A), "skinny_split",
- * "gemm_interleave" (tile -> workgroup map of zero-skipping products: 0 XCD-contiguous, 1 round-robin, 2 length-ranked),
- * "mid_split" (k-segments of lower-tiles-only products over triangular operands), "gemm_narrow" (64 x 32 tiles for
- *  T^T X with at most 32 columns), "grad_finish_dev" (dZ / d lengthscale finished on the device),
- * "h_resident" (non-RBF kernels: the K_nm build stores h(r) beside k for the gradient contraction; one more
- *  N x M array), "kbuild_pad" / "side_gemm_pad" (LDS padding of launches that share the CUs with a factorisation);
- * probes only (results are WRONG or unused): "gemm_alias", "dbg_gemm_kmode", "dbg_gemm_tri", "dbg_gemm_tile",
- *  "dbg_gemm_reps" (tools/alias_probe.sh, tools/mid_gemm_probe.py);
- * "sync_free" (default 1): a sparse evaluation queues all its phases for the statistics form the previous one ended in
- *  and waits for the device once, at the end, where it also reads the device's verdict (Cholesky info words,
- *  pivot-ratio proxy); if the verdict disagrees -- jitter needed, or the other form -- the evaluation is repeated with
- *  a synchronisation after each factorisation (0 = always that way).  Results are those of the form the
- *  pivot-ratio rule selects for the current Kmm either way;
- * "trace" (host-side phase timing to stderr). */
+/* Options (twelve; every other key is EDRGP_ERR_INVALID in the product library -- A/B switches of settled design
+ * decisions and timing probes exist in probe builds only, see edr-gp_amd/build.py and tools/README.md):
+ *  "chunk_rows"       rows of K_nm resident at a time (default 131072)
+ *  "stats_mode"       form of the row statistics: 0 automatic (pivot-ratio rule), 1 Gram form Phi = K_mn K_nm,
+ *                     2 stable form via K_nm Lm^-T (GPy's operation order)
+ *  "pivot_ratio_max"  automatic mode takes the stable form when (max / min diag Lm)^2 exceeds this (default 120)
+ *  "precision"        64 (default) or 32 = BASELINE config 5: K_nm stored in fp32 and the gradient contraction
+ *                     T = (K_nm S2 + ..) .* h(r), T^T [X | X.^2] on the fp32 MFMA with fp64 slab sums, for single-part
+ *                     kernels with D <= 64 while Kmm is conditioned for the Gram form; the bound itself stays fp64
+ *  "f32_phi"          with precision 32: also try the Gram matrix Phi in fp32; kept only if the factorisation of I + A
+ *                     succeeds without jitter and an error estimate stays below "f32_guard" (EDRGP_GET_MODE reports 3
+ *                     then; the bound is 1e-4..1e-3 accurate in that mode); "f32_ratio_max": fp32 Gram form only while
+ *                     (max / min diag Lm)^2 stays below this
+ *  "overlap"          side-stream use: 0 none, 1 the Kmm gradient term beside the gradient contraction and the K_nm
+ *                     build beside the Kmm factorisation, 2 the whole row pass beside the Kmm factorisation,
+ *                     3 (default) = 1, and 2 only for bound-only evaluations whose row pass is chunked (never with a
+ *                     communicator attached).  Same results in every setting
+ *  "sync_free"        (default 1) a sparse evaluation queues all its phases for the statistics form the previous one
+ *                     ended in and waits for the device once, at the end, where it also reads the device's verdict
+ *                     (Cholesky info words, pivot-ratio proxy); if the verdict disagrees -- jitter needed, or the other
+ *                     form -- the evaluation is repeated with a synchronisation after each factorisation (0 = always
+ *                     that way).  Results are those of the form the rule selects for the current Kmm either way
+ *  "posterior_reuse"  (default 1) edrgp_sparse_posterior right after a bound+gradient evaluation of the same state is
+ *                     served from that evaluation's factors
+ *  "pad_inducing"     (default 1) M > 256 not a multiple of 128: decoupled phantom inducing points up to the next
+ *                     multiple (exact: same bound, gradients and posterior)
+ *  "profile"          (0/1) HIP-event timing of the kernel families (edrgp_profile_get) */
 int  edrgp_set_option(edrgp_ctx* ctx, const char* key, double value);
 
 /* Training data (already validated / normalised by the host: check_X_y at

@@ -113,11 +113,7 @@ def test_potrf_with_inverse(hip, n):
     ref = sla.solve_triangular(np.linalg.cholesky(A), np.eye(n), lower=True)
     assert rel(Li, ref) < 1e-10
     assert rel(Li @ L, np.eye(n)) < 1e-11
-    hip.set_option("chol_inv_fused", 0)
-    try:
-        _, Li2, _ = hip.dbg_potrf_inv(A)
-    finally:
-        hip.set_option("chol_inv_fused", 1)
+    Li2 = hip.dbg_trtri(L)                   # the recursive-doubling inverse of the same factor
     assert rel(Li, Li2) < 1e-11
 
 
