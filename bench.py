@@ -15,8 +15,10 @@ One *step* = one fit+predict pass of the hot path over the resident batch:
   (edrgp/base.py:274).
 value = points processed by all ranks per second = n_gpus * N * steps / time.
 Inputs are resident in HBM before the timed region starts.  With N > 1 ranks the
-rows are sharded (weak scaling: N per GPU fixed) and Phi / K_mn y / gradient
-partials are sum-all-reduced over RCCL once per evaluation.
+rows are sharded and Phi / K_mn y / gradient partials are sum-all-reduced over
+RCCL once per evaluation: --scaling weak (default) keeps N rows on every GPU,
+--scaling strong splits ONE data set of N rows over the GPUs (value = N * steps /
+time then; the metric's literal "N = 100k at 1/2/4/8 GPUs").
 
 The same JSON line carries the log-ml evals/sec figure, the roofline of the
 dominant kernel (the fp64 MFMA syrk Phi = K_mn K_nm, timed with HIP events on the
@@ -200,6 +202,10 @@ def main():
     ap.add_argument("--D", type=int, default=32)
     ap.add_argument("--kind", default="RBF")
     ap.add_argument("--iters", type=int, default=ITERS_PER_FIT)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): --N rows on EVERY GPU; strong: --N rows in total, row-sharded over the GPUs "
+                         "(BASELINE's metric read literally: N = 100k at 1/2/4/8 GPUs; the replicated O(M^3) phases and "
+                         "the exchange are the Amdahl term there, DESIGN section 7)")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 = skip the CPU baseline leg (oracle on the host cores)")
     ap.add_argument("--check-sharding", action="store_true", help="run the sharded-vs-whole check (always on for --gpus > 1)")
     ap.add_argument("--host-allreduce", action="store_true",
@@ -245,7 +251,16 @@ def main():
         shard_check = sharding_check(h, dist, rank, world, local_rank)
 
     N, M, D = args.N, args.M, args.D
-    X, y, Z = synthetic(N, D, M, seed=RANK0_SEED + rank)
+    strong = (args.scaling == "strong") and world > 1
+    if strong:
+        # one data set of N rows for the whole job (every rank generates it and keeps its contiguous row block)
+        Xf, yf, Z = synthetic(N, D, M, seed=RANK0_SEED)
+        cuts = [(N * r) // world for r in range(world + 1)]
+        X, y = Xf[cuts[rank]:cuts[rank + 1]].copy(), yf[cuts[rank]:cuts[rank + 1]].copy()
+        del Xf, yf
+    else:
+        X, y, Z = synthetic(N, D, M, seed=RANK0_SEED + rank)
+    N_local = X.shape[0]
     h.set_data(X, y)                           # resident in HBM from here on
     h.set_inducing(Z)
     h.set_kernel([args.kind], [1.0], np.full((1, D), np.sqrt(D)), 0.01)
@@ -298,16 +313,16 @@ def main():
     mode = int(h.get("MODE", (1,))[0])
     # the dominant kernel alone on the GPU (no side-stream work beside it): same shape, device-made operand
     iso_ms = None
-    if rank == 0 and N % 16 == 0 and M % 128 == 0:
+    if rank == 0 and N_local % 16 == 0 and M % 128 == 0:
         try:
             h.sync()
-            iso_ms, _ = h.dbg_syrk_time(N, M, 0, 5)
+            iso_ms, _ = h.dbg_syrk_time(N_local, M, 0, 5)
         except Exception:
             iso_ms = None
 
     if rank == 0:
-        value = world * N * args.steps / elapsed
-        flops_per_launch = float(N) * M * (M + 1.0)                 # syrk, lower triangle only
+        value = (N if strong else world * N) * args.steps / elapsed
+        flops_per_launch = float(N_local) * M * (M + 1.0)           # syrk, lower triangle only
         avg_ms = syrk_ms / max(syrk_n, 1)
         achieved = flops_per_launch / (avg_ms * 1e-3) * 1e-12 if syrk_n else None
         traffic = None
@@ -325,12 +340,14 @@ def main():
         out = {
             "metric": "GP fit+predict throughput (points/sec) at N=100k,M=2048 per GPU; log-ml evals/sec alongside",
             "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "Cm: inducing-point sparse GP (VarDTC), N=%d rows per GPU, M=%d, D=%d, %s, fp64; "
+            "config": {"workload": "Cm: inducing-point sparse GP (VarDTC), N=%d rows %s, M=%d, D=%d, %s, fp64; "
                                    "step = %d bound+gradient evaluations + posterior + predict/predict_gradient on N rows"
-                                   % (N, M, D, args.kind, args.iters),
-                       "N_per_gpu": N, "M": M, "D": D, "kernel": args.kind, "evals_per_step": args.iters,
+                                   % (N, "in total, row-sharded (strong scaling)" if strong else "per GPU", M, D, args.kind,
+                                      args.iters),
+                       "N_per_gpu": N_local, "N_total": N if strong else world * N, "M": M, "D": D, "kernel": args.kind,
+                       "evals_per_step": args.iters,
                        "sharding": ("REHEARSAL on one device, exchange over gloo: not a measurement" if rehearsal else
                                     "rows; one RCCL sum-all-reduce of the packed lower triangle of Phi | K_mn y and of the "
                                     "gradient partials per evaluation") if world > 1 else "single GPU", "stats_form": {1: "gram", 2: "stable"}.get(mode, "?")},
@@ -339,6 +356,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel<128,128,true,true,1> (Phi = K_mn K_nm, fp64 MFMA syrk)",
                          "achieved": achieved, "peak": FP64_MFMA_SPEC_TFLOPS, "unit": "TFLOP/s",
                          "frac": (achieved / FP64_MFMA_SPEC_TFLOPS) if achieved else None, "traffic": traffic,
+                         "traffic_source": "profiles/pmc_syrk.json: FETCH_SIZE x 2 (gfx950 wide reads) + WRITE_SIZE per launch "
+                                           "of this kernel at this shape, collected by tools/pmc_collect.py in separate --pmc "
+                                           "passes -- a stored collection, not counters of this run" if traffic else None,
                          "avg_launch_ms": avg_ms, "launches": syrk_n, "flops_per_launch": flops_per_launch,
                          "peak_source": "AMD public MI355X fp64 matrix spec (not in the local guide)",
                          "peak_calibrated_tflops": calib_tf,

@@ -479,6 +479,7 @@ int edrgp_set_data(edrgp_ctx* ctx, const double* X, const double* y, int64_t N, 
     c->glob_valid = false;
     c->knm_train_valid = false;
     c->ep_begun = c->ep_valid = false;
+    c->base_y_valid = false;                    // y no longer belongs to the resident base rows of set_data_projected
     TRY(build_xtilde(c, c->X.d(), N, D, c->Xt.d()));
     TRY(build_xq(c, c->X.d(), N, D, c->Xq.d()));
     TRY(sum_sq(c, c->y.d(), N, c->scal.d() + SC_YY));
@@ -514,10 +515,13 @@ int edrgp_set_data_projected(edrgp_ctx* ctx, const double* Xbase, const double* 
         c->glob_valid = false;
         c->base_N = N;
         c->base_D = Dbase;
-    } else if (c->base_N != N || c->base_D != Dbase) {
-        set_error("set_data_projected: no resident base rows of shape %lld x %d", (long long)N, Dbase);
+        c->base_y_valid = true;
+    } else if (c->base_N != N || c->base_D != Dbase || !c->base_y_valid) {
+        // (edrgp_set_data overwrites y: the resident targets are then another data set's, even at the same N)
+        set_error("set_data_projected: no resident base rows / targets of shape %lld x %d", (long long)N, Dbase);
         return EDRGP_ERR_STATE;
     }
+    c->ep_begun = c->ep_valid = false;          // EP sites belong to the rows they were fitted on
     if (c->have_Z && c->D != d) c->have_Z = false;
     if (c->have_kernel && c->D != d) c->have_kernel = false;
     c->have_post = false;

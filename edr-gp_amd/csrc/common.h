@@ -285,6 +285,7 @@ struct Ctx {
     DBuf Xbase;                       // resident base rows of edrgp_set_data_projected (N x base_D)
     int64_t base_N = 0;
     int base_D = 0;
+    bool base_y_valid = false;        // c->y still holds the targets uploaded with Xbase (edrgp_set_data overwrites them)
     DBuf X, y, Z, Xt, Zt, Xq;         // Xt = [X|1|X.^2], Zt likewise for Z, Xq = [X|X.^2]
     bool have_data = false, have_Z = false, have_kernel = false;
     double yy_local = 0.0;

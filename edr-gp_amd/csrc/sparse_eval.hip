@@ -334,6 +334,9 @@ struct SparseEval {
         // predictions address K_nm with ld = number of real points (the stable form keeps K_nm in Knm, K_nm Li^T in W)
         c->knm_train_valid = k_resident && !padded;
         c->hnm_train_valid = c->knm_train_valid && h_built;
+        // sharded: what does not depend on the summed Phi (Kmm^-1 for the posterior / gradients) is released on the side
+        // stream NOW, so that it runs while the packed triangle is on the fabric; the sequence of collectives is the same
+        if (c->sharded()) TRY(kmmi_beside_phase3());
         TRY(allreduce_phi(c, Phi, M));
         return EDRGP_OK;
     }

@@ -50,9 +50,15 @@ class SparseGaussianProcessClassifier(ClassifierMixin, _BaseGP):
         self.Y_metadata = Y_metadata
         self.method = method
 
+    _MESSAGE = ("SparseGPClassification (EP on the DTC approximation) is not built on the MI355X path; "
+                "use GaussianProcessClassifier (dense EP) or a sparse regressor")
+
+    def fit(self, X, y, **opt_kws):
+        # refused before any validation or device work, so that clone()d copies inside EDR pipelines fail at once
+        raise NotImplementedError(self._MESSAGE)
+
     def _get_model(self, X, y, kernel):
-        raise NotImplementedError("SparseGPClassification (EP on the DTC approximation) is not built on the MI355X path; "
-                                  "use GaussianProcessClassifier (dense EP) or a sparse regressor")
+        raise NotImplementedError(self._MESSAGE)
 
     def predict(self, X):
         return super().predict(X) > 0.5

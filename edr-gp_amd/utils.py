@@ -123,6 +123,13 @@ class SVDTransformer(BaseEstimator, TransformerMixin):
         is defined up to sign; here each component is oriented along the column sums of X (largest entry positive
         when those are unknown or orthogonal to it)."""
         w, V = np.linalg.eigh(G.gram)
+        # Accuracy floor: forming X^T X squares the condition number, so singular values below ~1e-6 of the largest
+        # (eigenvalues below 1e-12 of the largest) are rounding noise here where the SVD of X resolves them.  A
+        # numerically rank-deficient gradient matrix therefore goes back to the dense decomposition whenever the
+        # matrix itself can be fetched (the reference's path, edrgp/utils.py:140); without it the noise eigenvalues
+        # are clipped to 0 and only their (arbitrary, orthonormal) directions remain.
+        if w.max() > 0 and w.min() < 1e-12 * w.max() and getattr(G, "_fetch", None) is not None:
+            return self.fit(G.materialize())
         order = np.argsort(w)[::-1]
         var = np.clip(w[order], 0.0, None)
         Vh = V[:, order].T.copy()

@@ -216,3 +216,34 @@ def test_oracle_gradients_x_gemm_form(kind):
         a = k.gradients_X(dLs, X)
         b = k.gradients_X(dLs, X, gemm_form=True)
         assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(a).max())
+
+
+def test_fit_gram_falls_back_on_rank_deficient_gradients():
+    """SVDTransformer.fit_gram works on G^T G, which squares the condition number: a numerically rank-deficient
+    gradient matrix (singular values below 1e-6 of the largest) goes back to the dense SVD when the matrix can be
+    fetched, and then reproduces ``fit`` exactly; a full-rank one stays on the Gram path."""
+    from edrgp_amd.utils import GradientGram, SVDTransformer
+    rng = np.random.default_rng(11)
+    B = rng.standard_normal((400, 3))
+    G = B @ rng.standard_normal((3, 6)) + 1e-9 * rng.standard_normal((400, 6))      # rank 3 + noise at 1e-9
+    fetched = []
+    gram = GradientGram(G.T @ G, 400, G.sum(0), fetch=lambda: fetched.append(1) or G)
+    a = SVDTransformer(n_components=0.999999999999).fit_gram(gram)
+    b = SVDTransformer(n_components=0.999999999999).fit(G)
+    assert fetched, "the dense matrix was not fetched"
+    assert a.components_.shape == b.components_.shape
+    assert np.allclose(a.components_, b.components_) and np.allclose(a.subspace_variance_, b.subspace_variance_)
+    # full rank: no fetch, same leading subspace
+    G2 = rng.standard_normal((400, 6))
+    fetched.clear()
+    a2 = SVDTransformer(n_components=2).fit_gram(GradientGram(G2.T @ G2, 400, G2.sum(0), fetch=lambda: fetched.append(1) or G2))
+    b2 = SVDTransformer(n_components=2).fit(G2)
+    assert not fetched
+    assert np.allclose(np.abs(a2.components_ @ b2.components_.T), np.eye(2), atol=1e-8)
+
+
+def test_sparse_classifier_refuses_at_fit():
+    from edrgp_amd.gp_model import SparseGaussianProcessClassifier
+    est = clone(SparseGaussianProcessClassifier(num_inducing=5))        # constructible and clonable ...
+    with pytest.raises(NotImplementedError):                            # ... and refused before any work
+        est.fit(np.zeros((4, 2)), np.array([0, 1, 0, 1]))
