@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void scale_norm_tile_kernel(const double* __re
 }
 
 static void launch_scale_norm(Ctx* c, const double* X, int64_t rows, int D, const double* invl, double* Xs, double* xn) {
-    if (D <= 64 && rows >= 4096)
+    if (D <= 64)             // (also for the 2048 rows of Z: the row-per-thread form took 13-21 us there, latency-bound)
         hipLaunchKernelGGL(scale_norm_tile_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256),
                            (size_t)64 * (D + 1) * sizeof(double), c->stream, X, rows, D, invl, Xs, xn);
     else
