@@ -326,7 +326,8 @@ def main():
         avg_ms = syrk_ms / max(syrk_n, 1)
         achieved = flops_per_launch / (avg_ms * 1e-3) * 1e-12 if syrk_n else None
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_syrk.json")
+        pmc_name = "r03_pmc_syrk.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_syrk.json")) else "pmc_syrk.json"
+        pmc_path = os.path.join(ROOT, "profiles", pmc_name)
         if os.path.exists(pmc_path):
             try:
                 traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
@@ -356,7 +357,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_f64_kernel<128,128,true,true,1> (Phi = K_mn K_nm, fp64 MFMA syrk)",
                          "achieved": achieved, "peak": FP64_MFMA_SPEC_TFLOPS, "unit": "TFLOP/s",
                          "frac": (achieved / FP64_MFMA_SPEC_TFLOPS) if achieved else None, "traffic": traffic,
-                         "traffic_source": "profiles/pmc_syrk.json: FETCH_SIZE x 2 (gfx950 wide reads) + WRITE_SIZE per launch "
+                         "traffic_source": "profiles/" + pmc_name + ": FETCH_SIZE x 2 (gfx950 wide reads) + WRITE_SIZE per launch "
                                            "of this kernel at this shape, collected by tools/pmc_collect.py in separate --pmc "
                                            "passes -- a stored collection, not counters of this run" if traffic else None,
                          "avg_launch_ms": avg_ms, "launches": syrk_n, "flops_per_launch": flops_per_launch,

@@ -57,6 +57,8 @@ def subspace_variance_ratio(X, V):
     (edrgp/utils.py:27-55).  X may be a ``GradientGram``: ||X v||^2 = v^T (X^T X) v."""
     gram = V.T @ V
     ortho = np.allclose(gram, np.eye(V.shape[1]))
+    if isinstance(X, GradientGram) and X._dense is not None:
+        X = X._dense          # already fetched (e.g. by fit_gram below its accuracy floor): the reference's own arithmetic
     if isinstance(X, GradientGram):
         if ortho:
             proj = np.sqrt(np.clip(np.einsum("ij,ik,kj->j", V, X.gram, V), 0.0, None))
