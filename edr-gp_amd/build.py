@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libedrgp_hip.so")
-SOURCES = ["api.hip", "sparse_eval.hip", "sweep_eval.hip", "ep_eval.hip", "la_gemm.hip", "la_gemm32.hip", "la_chol.hip", "la_vec.hip", "gp_kernels.hip", "comm.hip", "calib.hip"]
+SOURCES = ["api.hip", "sparse_eval.hip", "sweep_eval.hip", "ep_eval.hip", "la_gemm.hip", "la_chol.hip", "la_vec.hip", "gp_kernels.hip", "comm.hip", "calib.hip"]
 HEADERS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + \
           [os.path.join(HERE, "..", "include", "edrgp_hip.h")]
 # probe builds (never the product): EDRGP_BUILD_VARIANT=<name> -> libedrgp_hip_<name>.so; "stamps" adds

@@ -409,7 +409,7 @@ int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
     else if (!std::strcmp(key, "f32_guard")) c->f32_guard = value;
     else if (!std::strcmp(key, "f32_phi")) { c->f32_phi = (value != 0.0); c->phi32_bad = false; }
     else if (!std::strcmp(key, "precision")) {
-        // 64 (default): fp64 throughout.  32: the N-proportional row pass in fp32 (la_gemm32.hip)
+        // 64 (default): fp64 throughout.  32: the N-proportional row pass in fp32 (la_gemm.hip, float instantiation)
         if ((int)value != 32 && (int)value != 64) { set_error("precision must be 32 or 64"); return EDRGP_ERR_INVALID; }
         c->precision = (int)value;
         c->have_post = false;

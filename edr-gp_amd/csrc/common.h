@@ -203,7 +203,7 @@ int predict_chunk(Ctx* c, const KSpec& ks, const double* Xs, int64_t rows, const
                   bool h_ready = false);
 int vec_axpy(Ctx* c, int64_t n, double a, const double* x, double* y);   // y += a x
 
-// ------------------------------------------------------- fp32 row pass (la_gemm32.hip)
+// ------------------------------------------------------- fp32 row pass (la_gemm.hip, float instantiation)
 int gemm32(Ctx* c, bool transA, bool transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
            float* C, int ldc);
 int syrk32_tn(Ctx* c, const float* K, int64_t rows, int M, int ldk, double* Phi, int ldphi, bool accumulate);
