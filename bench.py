@@ -319,6 +319,13 @@ def main():
             iso_ms, _ = h.dbg_syrk_time(N_local, M, 0, 5)
         except Exception:
             iso_ms = None
+    chol_iso_ms = None
+    if rank == 0:
+        try:
+            Bm = np.random.default_rng(5).standard_normal((M, M))
+            chol_iso_ms = h.dbg_potrf_time(Bm @ Bm.T / M + np.eye(M), 5)
+        except Exception:
+            chol_iso_ms = None
 
     if rank == 0:
         value = (N if strong else world * N) * args.steps / elapsed
@@ -382,7 +389,11 @@ def main():
                          "flops": 2.0 * M ** 3 / 3.0,
                          "tflops": (2.0 * M ** 3 / 3.0 / (chol_ms / chol_n * 1e-3) * 1e-12) if chol_n else None,
                          "frac_of_fp64_mfma_peak": (2.0 * M ** 3 / 3.0 / (chol_ms / chol_n * 1e-3) * 1e-12 / FP64_MFMA_SPEC_TFLOPS)
-                         if chol_n else None},
+                         if chol_n else None,
+                         # the same factorisation + inverse with the GPU to itself (random SPD matrix, 5 runs)
+                         "isolated_ms": chol_iso_ms,
+                         "isolated_frac_of_fp64_mfma_peak": (2.0 * M ** 3 / 3.0 / (chol_iso_ms * 1e-3) * 1e-12 /
+                                                             FP64_MFMA_SPEC_TFLOPS) if chol_iso_ms else None},
         }
         if shard_check is not None:
             out["sharding_check"] = shard_check

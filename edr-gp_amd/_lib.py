@@ -90,6 +90,7 @@ PROTOTYPES = {
     "edrgp_dbg_syrk32": [_ctx_p, _c_float_p, ctypes.c_int64, ctypes.c_int, _c_double_p],
     "edrgp_dbg_potrf": [_ctx_p, _c_double_p, ctypes.c_int, _c_int_p],
     "edrgp_dbg_potrf_inv": [_ctx_p, _c_double_p, ctypes.c_int, _c_int_p, _c_double_p],
+    "edrgp_dbg_potrf_time": [_ctx_p, _c_double_p, ctypes.c_int, ctypes.c_int, _c_double_p],
     "edrgp_dbg_trtri": [_ctx_p, _c_double_p, _c_double_p, ctypes.c_int],
     "edrgp_dbg_syrk": [_ctx_p, _c_double_p, ctypes.c_int64, ctypes.c_int, _c_double_p],
     "edrgp_dbg_syrk_time": [_ctx_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_double_p, _c_double_p],

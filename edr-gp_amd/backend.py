@@ -320,6 +320,13 @@ class HipGP:
         check(self._lib.edrgp_dbg_potrf_inv(self._ctx, dptr(L), L.shape[0], ctypes.byref(info), dptr(Li)))
         return L, Li, info.value
 
+    def dbg_potrf_time(self, A, reps=5):
+        """Average time (ms) of the production factorisation + inverse of the factor alone on the SPD matrix A."""
+        A = as_f64(A)
+        ms = ctypes.c_double(0.0)
+        check(self._lib.edrgp_dbg_potrf_time(self._ctx, dptr(A), A.shape[0], reps, ctypes.byref(ms)))
+        return ms.value
+
     def dbg_trtri(self, L):
         L = as_f64(L)
         out = np.empty_like(L)

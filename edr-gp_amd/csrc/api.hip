@@ -925,6 +925,40 @@ int edrgp_dbg_potrf_inv(edrgp_ctx* ctx, double* A, int n, int* info, double* Lin
     return EDRGP_OK;
 }
 
+// Times `reps` runs of the production factorisation-with-inverse (potrf_inv_lower) alone on the n x n SPD matrix A:
+// each run starts from a fresh device copy of A, events bracket the factorisation only.
+int edrgp_dbg_potrf_time(edrgp_ctx* ctx, const double* A, int n, int reps, double* avg_ms) {
+    CTX(ctx);
+    if (!A || n <= 0 || reps < 1 || !avg_ms) { set_error("dbg_potrf_time: bad input"); return EDRGP_ERR_INVALID; }
+    DBuf d0, dA, dI;
+    const size_t bytes = (size_t)n * n * sizeof(double);
+    TRY(d0.reserve(bytes));
+    TRY(dA.reserve(bytes));
+    TRY(dI.reserve(bytes));
+    TRY(c->info.reserve(4 * sizeof(int)));
+    HIP_TRY(hipMemcpy(d0.d(), A, bytes, hipMemcpyHostToDevice));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    double total = 0.0;
+    int s = EDRGP_OK;
+    for (int r = -1; r < reps && s == EDRGP_OK; ++r) {      // r = -1: untimed warm-up
+        HIP_TRY(hipMemcpyAsync(dA.d(), d0.d(), bytes, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipEventRecord(e0, c->stream));
+        s = potrf_inv_lower(c, dA.d(), n, n, static_cast<int*>(c->info.p), dI.d(), n);
+        HIP_TRY(hipEventRecord(e1, c->stream));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        if (r >= 0) total += ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    c->drain_events();
+    *avg_ms = total / reps;
+    return s;
+}
+
 int edrgp_dbg_trtri(edrgp_ctx* ctx, const double* L, double* Linv, int n) {
     CTX(ctx);
     DBuf dL, dI;

@@ -23,16 +23,18 @@ namespace {
 
 // K[z][n][m] = var k(R2[n][m] il2[z]) (+ jitter where n == m, for square matrices), z = blockIdx.z.
 // A workgroup owns 64 rows x 512 columns (thread: two adjacent columns, 16-byte accesses) and, when y is given,
-// leaves the partial column sums  sum_rows K y  of its rows in bpart[row tile][column].
+// leaves the partial column sums  sum_rows K y  of its rows in bpart[row tile][column].  H (optional, same layout as
+// one K): h(r) = k'(r) / r of the same pass, what the mean Jacobian of a non-RBF kernel multiplies (kfun.h); K may
+// then be null (the gradient pass of a grid whose K_g were not kept).
 __global__ __launch_bounds__(256) void k_from_r2_kernel(const double* __restrict__ R2, int64_t rows, int M,
                                                        const double* __restrict__ il2, double var, int kind,
                                                        double jitter, const double* __restrict__ y,
                                                        double* __restrict__ K, long long strideK,
-                                                       double* __restrict__ bpart) {
+                                                       double* __restrict__ bpart, double* __restrict__ H) {
     const int c0 = ((int)blockIdx.x * 256 + (int)threadIdx.x) * 2;
     const int64_t r0 = (int64_t)blockIdx.y * 64;
     const double s = il2[blockIdx.z];
-    double* Kz = K + (long long)blockIdx.z * strideK;
+    double* Kz = (K != nullptr) ? K + (long long)blockIdx.z * strideK : nullptr;
     if (c0 >= M) return;
     const bool two = (c0 + 1 < M);
     const bool vec = two && ((M & 1) == 0);
@@ -48,18 +50,28 @@ __global__ __launch_bounds__(256) void k_from_r2_kernel(const double* __restrict
             q0 = R2[off];
             if (two) q1 = R2[off + 1];
         }
-        double k0, k1 = 0.0, h;
-        edrgp_kfun(kind, var, q0 * s, k0, h);
-        if (two) edrgp_kfun(kind, var, q1 * s, k1, h);
+        double k0, k1 = 0.0, h0, h1 = 0.0;
+        edrgp_kfun(kind, var, q0 * s, k0, h0);
+        if (two) edrgp_kfun(kind, var, q1 * s, k1, h1);
         if (jitter != 0.0) {
             if (r0 + r == c0) k0 += jitter;
             if (r0 + r == c0 + 1) k1 += jitter;
         }
-        if (vec) {
-            *reinterpret_cast<double2*>(Kz + off) = double2{k0, k1};
-        } else {
-            Kz[off] = k0;
-            if (two) Kz[off + 1] = k1;
+        if (Kz != nullptr) {
+            if (vec) {
+                *reinterpret_cast<double2*>(Kz + off) = double2{k0, k1};
+            } else {
+                Kz[off] = k0;
+                if (two) Kz[off + 1] = k1;
+            }
+        }
+        if (H != nullptr) {
+            if (vec) {
+                *reinterpret_cast<double2*>(H + off) = double2{h0, h1};
+            } else {
+                H[off] = h0;
+                if (two) H[off + 1] = h1;
+            }
         }
         if (y != nullptr) {
             const double yr = y[r0 + r];
@@ -74,7 +86,7 @@ __global__ __launch_bounds__(256) void k_from_r2_kernel(const double* __restrict
 }
 
 int k_from_r2(Ctx* c, const double* R2, int64_t rows, int M, const double* il2_dev, int G, double var, int kind,
-              double jitter, const double* y, double* K, long long strideK, double* bvec) {
+              double jitter, const double* y, double* K, long long strideK, double* bvec, double* H = nullptr) {
     const int tiles_r = (int)((rows + 63) / 64);
     double* bpart = nullptr;
     if (y != nullptr) {
@@ -83,7 +95,7 @@ int k_from_r2(Ctx* c, const double* R2, int64_t rows, int M, const double* il2_d
     }
     dim3 grid((unsigned)((M + 511) / 512), (unsigned)tiles_r, (unsigned)G);
     hipLaunchKernelGGL(k_from_r2_kernel, grid, dim3(256), 0, c->stream, R2, rows, M, il2_dev, var, kind, jitter, y, K, strideK,
-                       bpart);
+                       bpart, H);
     HIP_TRY(hipGetLastError());
     if (y != nullptr) TRY(col_reduce(c, bpart, tiles_r, M, bvec));
     return EDRGP_OK;
@@ -105,7 +117,8 @@ int sweep_scales(Ctx* c, int G, const double* ls, double var, double noise_var, 
     const int D = c->D, M = c->M;
     const int64_t N = c->N;
     if (G < 1 || G > 64 || !ls || !bounds || !(var > 0.0) || !(noise_var >= 0.0)) { set_error("sweep_scales: bad arguments"); return EDRGP_ERR_INVALID; }
-    if (kind != EDRGP_KERN_RBF) { set_error("sweep_scales: RBF only (the per-unit path serves the other kernels)"); return EDRGP_ERR_INVALID; }
+    if (kind != EDRGP_KERN_RBF && kind != EDRGP_KERN_MATERN32 && kind != EDRGP_KERN_MATERN52) { set_error("sweep_scales: RBF, Matern32 or Matern52"); return EDRGP_ERR_INVALID; }
+    const bool rbf = (kind == EDRGP_KERN_RBF);
     if (!c->mfma_kbuild) { set_error("sweep_scales needs the MFMA kernel build (option mfma_kbuild)"); return EDRGP_ERR_STATE; }
     if (M <= 64 || M > 3072 || N > 0x7fffffffLL || N < M) { set_error("sweep_scales: needs 64 < M <= 3072 and N >= M"); return EDRGP_ERR_INVALID; }
     for (int g = 0; g < G; ++g) if (!(ls[g] > 0.0)) { set_error("sweep_scales: lengthscale must be positive"); return EDRGP_ERR_INVALID; }
@@ -200,13 +213,15 @@ int sweep_scales(Ctx* c, int G, const double* ls, double var, double noise_var, 
     // ---- row passes, back to back
     for (int g = 0; g < G; ++g) {
         if (mode[g] < 0) continue;
-        double* Kg = keep_k ? c->sw_kall.d() + (size_t)g * k_stride : c->Knm.d();
+        // RBF: h(r) = -k(r), the kept K_g serves the gradient pass; Matern: K_g is scratch and h(r) is what is kept
+        double* Kg = (keep_k && rbf) ? c->sw_kall.d() + (size_t)g * k_stride : c->Knm.d();
+        double* Hg = (keep_k && !rbf) ? c->sw_kall.d() + (size_t)g * k_stride : nullptr;
         double* Phi = PhiB + (size_t)g * phi_stride;
         double* bvec = Phi + MM;
         {
             ProfScope ps(c, EDRGP_PROF_KBUILD);
             TRY(k_from_r2(c, R2nm, N, M, il2 + g, 1, var, kind, 0.0, mode[g] == 1 ? c->y.d() : nullptr, Kg, 0,
-                          mode[g] == 1 ? bvec : nullptr));
+                          mode[g] == 1 ? bvec : nullptr, Hg));
         }
         const double* S = Kg;
         if (mode[g] == 2) {
@@ -284,7 +299,7 @@ int sweep_scales(Ctx* c, int G, const double* ls, double var, double noise_var, 
         }
     }
 
-    // ---- gradient Gram matrices: J = d mean / d x at the training rows (RBF: one N x D x M product on K_g)
+    // ---- gradient Gram matrices: J = d mean / d x at the training rows (one N x D x M product on K_g, or on h_g(r))
     double* d_gram = nullptr;
     if (grams != nullptr) {
         TRY(c->g2.reserve(((size_t)G * ((size_t)D * D + D) + (size_t)N + 8) * sizeof(double)));
@@ -299,18 +314,20 @@ int sweep_scales(Ctx* c, int G, const double* ls, double var, double noise_var, 
         for (int g = 0; g < G; ++g) {
             double* Gg = d_gram + (size_t)g * ((size_t)D * D + D);
             if (mode[g] < 0) { HIP_TRY(hipMemsetAsync(Gg, 0, ((size_t)D * D + D) * sizeof(double), c->stream)); continue; }
-            double* Kg = keep_k ? c->sw_kall.d() + (size_t)g * k_stride : c->Knm.d();
+            double* Kg = keep_k ? c->sw_kall.d() + (size_t)g * k_stride : c->Knm.d();      // K_g (RBF) or h_g (Matern)
             if (!keep_k) {
                 ProfScope ps(c, EDRGP_PROF_KBUILD);
-                TRY(k_from_r2(c, R2nm, N, M, il2 + g, 1, var, kind, 0.0, nullptr, Kg, 0, nullptr));
+                TRY(k_from_r2(c, R2nm, N, M, il2 + g, 1, var, kind, 0.0, nullptr, rbf ? Kg : nullptr, 0, nullptr,
+                              rbf ? nullptr : Kg));
             }
             KSpec ks;
             ks.nparts = 1; ks.D = D;
             for (int p = 0; p < EDRGP_MAX_PARTS; ++p) { ks.kind[p] = 0; ks.var[p] = 0.0; }
             ks.kind[0] = kind; ks.var[0] = var;
             ks.invl = invl_g + (size_t)g * D;
+            // (Matern: the Jacobian is H_g [diag(wv) Z | wv] on the matrix pipe, K_g itself is not read)
             TRY(predict_chunk(c, ks, c->X.d(), N, c->Z.d(), c->Zt.d(), M, vecs + (size_t)g * 4 * M + 3 * M, nullptr, var, Kg,
-                              c->W.d(), GT, nullptr, nullptr, o_jac, true));
+                              c->W.d(), GT, nullptr, nullptr, o_jac, true, rbf ? nullptr : Kg, !rbf));
             TRY(gemm(c, true, false, D, D, (int)N, 1.0, o_jac, D, o_jac, D, 0.0, Gg, D));
             TRY(gemm(c, true, false, D, 1, (int)N, 1.0, o_jac, D, d_ones, 1, 0.0, Gg + (size_t)D * D, 1));
         }

@@ -43,7 +43,7 @@ def _sweep_worker(h, close, X, y, Z_rows, projections, n_scales, kind, variance,
             base_sent = True
             h.set_inducing(np.ascontiguousarray(X[Z_rows] @ W))
             todo = list(mine)
-            if batch and want_gram and not want_gradients and kind == "RBF" and 64 < len(Z_rows) <= 3072:
+            if batch and want_gram and not want_gradients and kind in ("RBF", "Matern32", "Matern52") and 64 < len(Z_rows) <= 3072:
                 # the scales of this candidate as ONE batch on the device (edrgp_sweep_scales): squared distances
                 # formed once, every factorisation of the 2 x len(mine) advancing in the same launches
                 bounds, grams, gsums, modes = h.sweep_scales(scales[todo], variance, noise, kind, want_gram=True)

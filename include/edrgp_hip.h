@@ -192,8 +192,8 @@ int  edrgp_ep_posterior(edrgp_ctx* ctx, double* lml);
 
 /* BASELINE config 4 as a batch: for the resident training rows (edrgp_set_data / edrgp_set_data_projected) and
  * inducing inputs, the unit of work of the EDR loop at fixed hyper-parameters (edrgp/base.py:460-461: fit on the
- * projected rows, posterior-mean gradients at the training rows) for `nscales` isotropic RBF length-scales at one
- * variance / noise: bounds[nscales] (Titsias bound), grams[nscales * D * D] (J^T J of the mean Jacobian at the
+ * projected rows, posterior-mean gradients at the training rows) for `nscales` isotropic length-scales of one stationary kernel (`kind`:
+ * RBF, Matern32 or Matern52) at one variance / noise: bounds[nscales] (Titsias bound), grams[nscales * D * D] (J^T J of the mean Jacobian at the
  * training rows; may be NULL), gsums[nscales * D] (column sums of J; may be NULL), modes[nscales] (1 Gram form,
  * 2 stable form, -1: this scale needs jitchol jitter -- its bound is NaN and the caller evaluates it with
  * edrgp_set_kernel + edrgp_sparse_posterior + edrgp_predict_train_gram, which give the same numbers as the batch does
@@ -236,6 +236,8 @@ int  edrgp_dbg_syrk32(edrgp_ctx* ctx, const float* K, int64_t N, int M, double* 
 int  edrgp_dbg_potrf(edrgp_ctx* ctx, double* A, int n, int* info);
 /* factor and inverse of the factor out of the same launches: A <- L, Linv <- L^-1 */
 int  edrgp_dbg_potrf_inv(edrgp_ctx* ctx, double* A, int n, int* info, double* Linv);
+/* average time (ms) of `reps` runs of that factorisation-with-inverse alone on the SPD matrix A (bench.py) */
+int  edrgp_dbg_potrf_time(edrgp_ctx* ctx, const double* A, int n, int reps, double* avg_ms);
 int  edrgp_dbg_trtri(edrgp_ctx* ctx, const double* L, double* Linv, int n);
 int  edrgp_dbg_syrk(edrgp_ctx* ctx, const double* K, int64_t N, int M, double* Phi);
 /* times the production Phi = K^T K kernel alone on a device-generated K (bench.py "isolated" figure) */

@@ -92,8 +92,9 @@ def test_sweep_concurrent_contexts_match_sequential(hip):
         assert np.array_equal(a["gram"], b["gram"])
 
 
-@pytest.mark.parametrize("N,D,M,dcs", [(3000, 12, 96, (12, 7)), (5000, 10, 300, (10,))])
-def test_sweep_batched_scales_equal_per_unit_path(hip, N, D, M, dcs):
+@pytest.mark.parametrize("N,D,M,dcs,kind", [(3000, 12, 96, (12, 7), "RBF"), (5000, 10, 300, (10,), "RBF"),
+                                             (3000, 12, 96, (12, 7), "Matern52"), (5000, 10, 300, (10,), "Matern32")])
+def test_sweep_batched_scales_equal_per_unit_path(hip, N, D, M, dcs, kind):
     """edrgp_sweep_scales (all length-scales of a candidate as one batch: distances formed once, batched
     factorisations) gives the numbers of the per-unit path -- bound 1e-10, gradient Gram matrix 1e-8 -- and of the
     oracle; the grid spans both statistics forms (wide length-scales take the stable one)."""
@@ -104,8 +105,8 @@ def test_sweep_batched_scales_equal_per_unit_path(hip, N, D, M, dcs):
     y = (y - y.mean()) / y.std()
     projections = [np.linalg.qr(rng.standard_normal((D, dc)))[0] for dc in dcs]
     Zrows = rng.permutation(N)[:M]
-    bat = projection_sweep(X, y, Zrows, projections, n_scales=8, want_gram=True, hip=hip)
-    seq = projection_sweep(X, y, Zrows, projections, n_scales=8, want_gram=True, hip=hip, batch=False)
+    bat = projection_sweep(X, y, Zrows, projections, n_scales=8, want_gram=True, hip=hip, kind=kind)
+    seq = projection_sweep(X, y, Zrows, projections, n_scales=8, want_gram=True, hip=hip, batch=False, kind=kind)
     assert [(r["candidate"], r["scale"]) for r in bat] == [(r["candidate"], r["scale"]) for r in seq]
     forms = set()
     for a, b in zip(bat, seq):
@@ -113,13 +114,15 @@ def test_sweep_batched_scales_equal_per_unit_path(hip, N, D, M, dcs):
         assert abs(a["bound"] - b["bound"]) <= 1e-10 * max(abs(b["bound"]), float(N)), (a["candidate"], a["scale"])
         assert np.abs(a["gram"] - b["gram"]).max() <= 1e-8 * np.abs(b["gram"]).max()
         assert np.abs(a["gsum"] - b["gsum"]).max() <= 1e-8 * max(np.abs(b["gsum"]).max(), np.sqrt(np.abs(b["gram"]).max()))
-    assert forms >= {1, 2}                 # both statistics forms occurred in the batch
-    # and against the oracle for two of the records (one per form)
-    for form in (1, 2):
+    assert 1 in forms and all(r.get("form") in (1, 2) for r in bat)       # every record came out of the batch
+    if kind == "RBF":
+        assert forms >= {1, 2}             # both statistics forms occurred in the batch
+    # and against the oracle for one record per form
+    for form in sorted(forms):
         rec = next(r for r in bat if r.get("form") == form)
         W = projections[rec["candidate"]]
         Xp = X @ W
-        kern = go.make_kernel(["RBF"], Xp.shape[1], [dict(variance=1.0, lengthscale=rec["lengthscale"])])
+        kern = go.make_kernel([kind], Xp.shape[1], [dict(variance=1.0, lengthscale=rec["lengthscale"])])
         inf = go.vardtc_inference(kern, Xp, Xp[Zrows], 0.01, y[:, None])
         ref = inf["log_marginal"][0, 0]
         assert abs(rec["bound"] - ref) <= 1e-9 * max(abs(ref), float(N))
