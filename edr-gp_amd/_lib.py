@@ -73,6 +73,10 @@ PROTOTYPES = {
     "edrgp_ep_set_sites": [_ctx_p, _c_double_p, _c_double_p, ctypes.c_double],
     "edrgp_ep_lml_grad": [_ctx_p, _c_double_p, _c_double_p, _c_double_p],
     "edrgp_ep_posterior": [_ctx_p, _c_double_p],
+    "edrgp_epdtc_begin": [_ctx_p, _c_double_p],
+    "edrgp_epdtc_sweep": [_ctx_p, _c_int_p, ctypes.c_double, ctypes.c_double, _c_double_p, _c_double_p],
+    "edrgp_epdtc_lml_grad": [_ctx_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p],
+    "edrgp_epdtc_posterior": [_ctx_p, _c_double_p],
     "edrgp_sweep_scales": [_ctx_p, ctypes.c_int, _c_double_p, ctypes.c_double, ctypes.c_double, ctypes.c_int, _c_double_p,
                            _c_double_p, _c_double_p, _c_int_p],
     "edrgp_get": [_ctx_p, ctypes.c_int, _c_double_p, ctypes.c_int64],

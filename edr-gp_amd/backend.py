@@ -209,6 +209,38 @@ class HipGP:
         check(self._lib.edrgp_ep_posterior(self._ctx, ctypes.byref(out)))
         return out.value
 
+    # -- sparse EP classifier (EPDTC); ep_finish / ep_get_sites / ep_set_sites are shared with the dense one
+    def epdtc_begin(self, y01):
+        y = as_f64(np.ravel(y01))
+        if y.shape[0] != self.N:
+            raise ValueError("labels must have one entry per resident row")
+        check(self._lib.edrgp_epdtc_begin(self._ctx, dptr(y)))
+
+    def epdtc_sweep(self, order, eta=1.0, delta=1.0):
+        order = np.ascontiguousarray(order, dtype=np.int32)
+        dt, dv = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        check(self._lib.edrgp_epdtc_sweep(self._ctx, order.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), float(eta),
+                                          float(delta), ctypes.byref(dt), ctypes.byref(dv)))
+        return dt.value, dv.value
+
+    def epdtc_lml(self):
+        out = ctypes.c_double(0.0)
+        check(self._lib.edrgp_epdtc_lml_grad(self._ctx, ctypes.byref(out), None, None, None))
+        return out.value
+
+    def epdtc_lml_grad(self):
+        lml = ctypes.c_double(0.0)
+        dvar = np.zeros(self.nparts)
+        dlen = np.zeros((self.nparts, self.D))
+        dZ = np.zeros((self.M, self.D))
+        check(self._lib.edrgp_epdtc_lml_grad(self._ctx, ctypes.byref(lml), dptr(dvar), dptr(dlen), dptr(dZ)))
+        return lml.value, dvar, dlen, dZ
+
+    def epdtc_posterior(self):
+        out = ctypes.c_double(0.0)
+        check(self._lib.edrgp_epdtc_posterior(self._ctx, ctypes.byref(out)))
+        return out.value
+
     def sweep_scales(self, lengthscales, variance=1.0, noise_var=0.01, kind="RBF", want_gram=True):
         """Bound (and J^T J / column sums of the mean Jacobian at the training rows) for a grid of isotropic
         length-scales of the resident rows and inducing inputs, as ONE batch on the device.

@@ -748,6 +748,35 @@ int edrgp_ep_posterior(edrgp_ctx* ctx, double* lml) {
     return ep_eval(c, false, true, lml, nullptr, nullptr);
 }
 
+int edrgp_epdtc_begin(edrgp_ctx* ctx, const double* y) {
+    CTX(ctx);
+    if (!y) { set_error("epdtc_begin: labels required"); return EDRGP_ERR_INVALID; }
+    return epdtc_begin(c, y);
+}
+
+int edrgp_epdtc_sweep(edrgp_ctx* ctx, const int* order, double eta, double delta, double* tau_diff, double* v_diff) {
+    CTX(ctx);
+    return epdtc_sweep(c, order, eta, delta, tau_diff, v_diff);
+}
+
+int edrgp_epdtc_lml_grad(edrgp_ctx* ctx, double* lml, double* dvar, double* dlen, double* dZ) {
+    CTX(ctx);
+    std::vector<double> gv, gl, gz;
+    const bool need_grad = (dvar || dlen || dZ);
+    TRY(epdtc_eval(c, need_grad, false, lml, &gv, &gl, &gz));
+    if (need_grad) {
+        if (dvar) std::memcpy(dvar, gv.data(), gv.size() * sizeof(double));
+        if (dlen) std::memcpy(dlen, gl.data(), gl.size() * sizeof(double));
+        if (dZ) std::memcpy(dZ, gz.data(), gz.size() * sizeof(double));
+    }
+    return EDRGP_OK;
+}
+
+int edrgp_epdtc_posterior(edrgp_ctx* ctx, double* lml) {
+    CTX(ctx);
+    return epdtc_eval(c, false, true, lml, nullptr, nullptr, nullptr);
+}
+
 int edrgp_sweep_scales(edrgp_ctx* ctx, int nscales, const double* lengthscales, double variance, double noise_var,
                        int kind, double* bounds, double* grams, double* gsums, int* modes) {
     CTX(ctx);

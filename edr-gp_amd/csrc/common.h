@@ -340,6 +340,7 @@ struct Ctx {
     DBuf sw_small, sw_r2, sw_mats, sw_kall;   // batched length-scale sweep (sweep_eval.hip)
     DBuf ep_K, ep_Sigma, ep_vec;      // EP classifier (ep_eval.hip): K, Sigma (N x N), site / cavity / moment vectors
     bool ep_begun = false, ep_valid = false;
+    bool ep_sparse = false, ep_fresh = false;   // the EP run in progress is EPDTC's; no site of it has been updated yet
     double ep_logZt = 0.0;            // log Z_tilde of the fitted sites
     double* kbuild_h = nullptr;       // the next MFMA build also stores h(r) here (ld = its K's): set around build_knm
     bool kbuild_r2 = false;           // the MFMA build stores r^2 instead of k(r^2) (set around the sweep's distance pass)

@@ -141,5 +141,10 @@ int ep_sweep(Ctx* c, const int* order, double eta, double delta, double* tau_dif
 int ep_finish(Ctx* c, double* log_Z_tilde);
 int ep_sites(Ctx* c, double* tau, double* v, const double* tau_in, const double* v_in, double logZt_in);
 int ep_eval(Ctx* c, bool need_grad, bool need_post, double* lml, std::vector<double>* dvar, std::vector<double>* dlen);
+// sparse EP classifier (EPDTC, ep_eval.hip); ep_finish / ep_sites serve both
+int epdtc_begin(Ctx* c, const double* y_host);
+int epdtc_sweep(Ctx* c, const int* order, double eta, double delta, double* tau_diff, double* v_diff);
+int epdtc_eval(Ctx* c, bool need_grad, bool need_post, double* lml, std::vector<double>* dvar, std::vector<double>* dlen,
+               std::vector<double>* dZ);
 
 }  // namespace edrgp

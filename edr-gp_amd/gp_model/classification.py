@@ -1,15 +1,14 @@
 """GP classifiers with the reference's constructor signatures (edrgp/gp_model/classification.py:38-45, :135-144).
 
 ``GaussianProcessClassifier`` stands on the dense EP model (``edrgp_amd.models.GPClassificationModel``: Bernoulli
-likelihood, probit link, expectation propagation on the device).  ``SparseGaussianProcessClassifier`` keeps the
-reference's interface but is not built: GPy's ``SparseGPClassification`` runs EP on the DTC approximation (EPDTC), a
-second inference algorithm outside the scope table's last row.
+likelihood, probit link, expectation propagation on the device), ``SparseGaussianProcessClassifier`` on
+``SparseGPClassificationModel`` (GPy's ``SparseGPClassification``: EP on the DTC approximation, EPDTC).
 """
 from __future__ import annotations
 
 from sklearn.base import ClassifierMixin
 
-from ..models import GPClassificationModel
+from ..models import GPClassificationModel, SparseGPClassificationModel
 from .base import _BaseGP
 
 
@@ -38,7 +37,13 @@ class GaussianProcessClassifier(ClassifierMixin, _BaseGP):
 
 
 class SparseGaussianProcessClassifier(ClassifierMixin, _BaseGP):
-    """Interface of the reference's sparse classifier; fitting raises ``NotImplementedError`` (EPDTC is not built)."""
+    """Parameters: kernels, kernel_options (as the regressors), likelihood (must be None: Bernoulli with the probit
+    link, GPy's default), Z / num_inducing (inducing inputs, or how many training rows to draw for them; default 10),
+    Y_metadata (must be None), method ('optimize' | 'optimize_restarts').  Attributes: ``estimator_``, ``n_features_``.
+
+    Stands on ``edrgp_amd.models.SparseGPClassificationModel`` (EPDTC on the device).  ``predict`` returns the class,
+    ``predict_proba`` the posterior probability of the second class, ``predict_gradient`` the gradient of the latent
+    posterior mean."""
 
     def __init__(self, kernels=None, kernel_options=None, likelihood=None, Z=None, num_inducing=10, Y_metadata=None,
                  method="optimize"):
@@ -50,15 +55,9 @@ class SparseGaussianProcessClassifier(ClassifierMixin, _BaseGP):
         self.Y_metadata = Y_metadata
         self.method = method
 
-    _MESSAGE = ("SparseGPClassification (EP on the DTC approximation) is not built on the MI355X path; "
-                "use GaussianProcessClassifier (dense EP) or a sparse regressor")
-
-    def fit(self, X, y, **opt_kws):
-        # refused before any validation or device work, so that clone()d copies inside EDR pipelines fail at once
-        raise NotImplementedError(self._MESSAGE)
-
     def _get_model(self, X, y, kernel):
-        raise NotImplementedError(self._MESSAGE)
+        return SparseGPClassificationModel(X, y, likelihood=self.likelihood, kernel=kernel, Z=self.Z,
+                                           num_inducing=self.num_inducing, Y_metadata=self.Y_metadata)
 
     def predict(self, X):
         return super().predict(X) > 0.5

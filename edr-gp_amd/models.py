@@ -151,11 +151,13 @@ class HipEvaluator:
         restored from the model when another model used the shared context in between."""
         h = self._sync_state(model)
         if model._sites is None:
-            h.ep_begin(model.Y[:, 0])
+            # dense EP on K(X, X), or EPDTC on the inducing-point posterior (same site updates and stop rule)
+            begin, sweep = (h.epdtc_begin, h.epdtc_sweep) if model.is_sparse else (h.ep_begin, h.ep_sweep)
+            begin(model.Y[:, 0])
             sweeps, stop = 0, False
             while not stop and sweeps < model.ep_max_iters:
                 order = np.random.permutation(model.num_data)          # upstream: a fresh permutation per sweep
-                d_tau, d_v = h.ep_sweep(order, model.ep_eta, model.ep_delta)
+                d_tau, d_v = sweep(order, model.ep_eta, model.ep_delta)
                 if sweeps > 0:
                     stop = (d_tau < model.ep_epsilon) and (d_v < model.ep_epsilon)
                 sweeps += 1
@@ -171,10 +173,15 @@ class HipEvaluator:
         return h
 
     def ep_lml(self, model):
-        return self._ensure_sites(model).ep_lml()
+        h = self._ensure_sites(model)
+        return h.epdtc_lml() if model.is_sparse else h.ep_lml()
 
     def ep_lml_grad(self, model):
-        return self._ensure_sites(model).ep_lml_grad()
+        """(lml, dvar, dlen, dZ); dZ is None for the dense classifier."""
+        h = self._ensure_sites(model)
+        if model.is_sparse:
+            return h.epdtc_lml_grad()
+        return h.ep_lml_grad() + (None,)
 
     def _ensure_posterior(self, model):
         classifier = getattr(model, "is_classifier", False)
@@ -182,7 +189,7 @@ class HipEvaluator:
         key = (self._sent.get("kern"), self._sent.get("Z"), self._sent.get("sites"))
         if self._sent.get("post") != key:
             if classifier:
-                model._lml_cache = h.ep_posterior()
+                model._lml_cache = h.epdtc_posterior() if model.is_sparse else h.ep_posterior()
             else:
                 model._lml_cache = h.sparse_posterior() if model.is_sparse else h.dense_posterior()
             self._sent["post"] = key
@@ -566,7 +573,7 @@ class GPClassificationModel(_GPModel):
         return super().parameter_names()[:-1]
 
     def _log_likelihood_gradients(self):
-        lml, dvar, dlen = self._evaluator.ep_lml_grad(self)
+        lml, dvar, dlen, dZ = self._evaluator.ep_lml_grad(self)
         self._lml_cache = lml
         g = []
         for i, p in enumerate(self.kern.parts):
@@ -575,7 +582,7 @@ class GPClassificationModel(_GPModel):
                 g.extend(np.asarray(dlen[i]).tolist())
             else:
                 g.append(float(np.sum(dlen[i])))
-        return lml, np.zeros(0), np.array(g, dtype=np.float64)
+        return lml, (np.zeros(0) if dZ is None else np.asarray(dZ).ravel()), np.array(g, dtype=np.float64)
 
     def _lml(self):
         if self._lml_cache is None:
@@ -611,6 +618,44 @@ class GPClassificationModel(_GPModel):
         return d
 
 
+class SparseGPClassificationModel(GPClassificationModel):
+    """Stands where ``GPy.models.SparseGPClassification`` stands (edrgp/gp_model/classification.py:147-149):
+    SparseGP with the Bernoulli / probit likelihood and EPDTC -- EP's site updates on the inducing-point (DTC)
+    posterior, then VarDTC with the pseudo-targets v / tau and the heteroscedastic precision tau.  Z defaults to
+    ``X[np.random.permutation(N)[:num_inducing]]`` (global numpy RNG, as upstream) and is an optimised parameter
+    beside the kernel's; the sites are fitted once per ``optimize()`` call (EPDTC's default ep_mode "alternated")."""
+    is_sparse = True
+
+    def __init__(self, X, Y, likelihood=None, kernel=None, Z=None, num_inducing=10, Y_metadata=None, evaluator=None,
+                 device=None):
+        if likelihood is not None:
+            raise NotImplementedError("only the default likelihood (Bernoulli, probit link) is on the MI355X path")
+        super().__init__(X, Y, kernel, Y_metadata, None, evaluator, device)
+        if Z is None:
+            i = np.random.permutation(self.num_data)[:min(num_inducing, self.num_data)]
+            Z = self.X[i].copy()
+        else:
+            Z = np.array(Z, dtype=np.float64)
+            assert Z.ndim == 2 and Z.shape[1] == self.input_dim
+        self.Z = np.ascontiguousarray(Z)
+        self.num_inducing = self.Z.shape[0]
+
+    def _free_block(self):
+        return self.Z.ravel()
+
+    def _set_free_block(self, vals):
+        self.Z = np.ascontiguousarray(np.asarray(vals, dtype=np.float64).reshape(self.Z.shape))
+        self._lml_cache = None
+
+    def parameter_names(self):
+        return ["inducing_inputs"] * self.Z.size + super().parameter_names()
+
+    def to_dict(self):
+        d = super().to_dict()
+        d["Z"] = self.Z
+        return d
+
+
 def load_model(path, evaluator=None, device=None):
     """Rebuilds a model written by ``pickle`` (an .npz archive: arrays and strings only)."""
     with np.load(path, allow_pickle=False) as f:
@@ -619,8 +664,11 @@ def load_model(path, evaluator=None, device=None):
                                           bool(f["ARD"][i])) for i in range(len(kinds))]
         kernel = parts[0] if len(parts) == 1 else _kern.Add(parts)
         normalizer = bool(f["normalize"])
-        if str(f["model"]) == "GPClassificationModel":
-            m = GPClassificationModel(f["X"], f["Y"], kernel, evaluator=evaluator, device=device)
+        if str(f["model"]) in ("GPClassificationModel", "SparseGPClassificationModel"):
+            if str(f["model"]) == "SparseGPClassificationModel":
+                m = SparseGPClassificationModel(f["X"], f["Y"], kernel=kernel, Z=f["Z"], evaluator=evaluator, device=device)
+            else:
+                m = GPClassificationModel(f["X"], f["Y"], kernel, evaluator=evaluator, device=device)
             if "ep_tau" in f.files:
                 m._set_sites(f["ep_tau"], f["ep_v"], float(f["ep_log_Z_tilde"]))
             return m

@@ -190,6 +190,20 @@ int  edrgp_ep_set_sites(edrgp_ctx* ctx, const double* tau, const double* v, doub
 int  edrgp_ep_lml_grad(edrgp_ctx* ctx, double* lml, double* dvar, double* dlen);
 int  edrgp_ep_posterior(edrgp_ctx* ctx, double* lml);
 
+/* Sparse GP classification (GPy SparseGPClassification = SparseGP + Bernoulli/probit + EPDTC, built at
+ * edrgp/gp_model/classification.py:147-149; optimised at gp_model/base.py:69, predicted at :187 / :222).
+ * Needs edrgp_set_data, edrgp_set_inducing and edrgp_set_kernel.  edrgp_epdtc_begin / edrgp_epdtc_sweep run
+ * EPDTC.expectation_propagation (one sweep per call, site order from the caller; tau_diff / v_diff = mean squared change
+ * of the sites against the previous sweep, EPBase._stop_criteria); edrgp_ep_finish, edrgp_ep_get_sites and
+ * edrgp_ep_set_sites serve both EP variants.  With the sites fixed, edrgp_epdtc_lml_grad is EPDTC.inference =
+ * VarDTC.inference(Y = v / tau, precision = tau, Z_tilde): bound, dvar[nparts], dlen[nparts * D], dZ[M * D] (any may be
+ * NULL; all NULL = bound only) and edrgp_epdtc_posterior leaves the woodbury vector / inverse resident for
+ * edrgp_predict*.  M <= 1024; replicas only (no row sharding). */
+int  edrgp_epdtc_begin(edrgp_ctx* ctx, const double* y);
+int  edrgp_epdtc_sweep(edrgp_ctx* ctx, const int* order, double eta, double delta, double* tau_diff, double* v_diff);
+int  edrgp_epdtc_lml_grad(edrgp_ctx* ctx, double* lml, double* dvar, double* dlen, double* dZ);
+int  edrgp_epdtc_posterior(edrgp_ctx* ctx, double* lml);
+
 /* BASELINE config 4 as a batch: for the resident training rows (edrgp_set_data / edrgp_set_data_projected) and
  * inducing inputs, the unit of work of the EDR loop at fixed hyper-parameters (edrgp/base.py:460-461: fit on the
  * projected rows, posterior-mean gradients at the training rows) for `nscales` isotropic length-scales of one stationary kernel (`kind`:

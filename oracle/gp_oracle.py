@@ -556,6 +556,130 @@ def ep_inference(kern, X, sites):
                 mu=mu, Sigma_diag=np.diag(Sigma).copy())
 
 
+# --------------------------------------------------------------------------
+# Sparse GP classification: GPy.models.SparseGPClassification = SparseGP + Bernoulli(probit) + EPDTC
+# (edrgp/gp_model/classification.py:147-149).  Restated: expectation_propagation.py (class EPDTC and
+# posteriorParamsDTC: the posterior lives on the DTC covariance Sigma = K_nm (K_mm + K_mn T K_nm)^-1 K_mn; a site
+# update refactors LLT = K_mm + K_mn T K_nm after its rank-one change; after every sweep everything is recomputed;
+# the stop rule and log Z_tilde are EPBase's, shared with the dense EP above) followed by VarDTC.inference with the
+# pseudo-targets mu_tilde = v / tau, the heteroscedastic precision tau and Z_tilde = log Z_tilde
+# (var_dtc.py, het_noise branches of _compute_dL_dpsi and _compute_log_marginal_likelihood).  As upstream, Lm is
+# jitchol(kern.K(Z)) WITHOUT the 1e-8 const_jitter (EPDTC.inference hands VarDTC its own Lm).
+# Parity status: unpinned (GPy absent); tests/test_classification.py checks the fixed point's own consistency
+# conditions and the gradients against finite differences of this bound.
+# --------------------------------------------------------------------------
+def epdtc_recompute(LLT0, Kmn, tau, v):
+    """posteriorParamsDTC._recompute (mu and the diagonal of Sigma = V^T V without forming the N x N matrix)."""
+    LLT = LLT0 + np.dot(Kmn * tau[None, :], Kmn.T)
+    L = jitchol(LLT)
+    V = dtrtrs(L, Kmn, lower=1)
+    mu = np.dot(V.T, np.dot(V, v))
+    return mu, np.sum(V * V, 0), LLT
+
+
+def expectation_propagation_dtc(Kmm, Kmn, y, order_fn=None, epsilon=1e-6, eta=1.0, delta=1.0, max_iters=10 ** 6):
+    """EPDTC.expectation_propagation (_init_approximations with no previous sites, _local_updates with
+    posteriorParamsDTC._update_rank1, _recompute + the eps floor on Sigma_diag after every sweep)."""
+    n = y.size
+    if order_fn is None:
+        order_fn = np.random.permutation
+    LLT0 = Kmm.copy()
+    Lm = jitchol(LLT0)
+    Vm = dtrtrs(Lm, Kmn, lower=1)
+    Sigma_diag = np.sum(Vm * Vm, 0) + 1e-8
+    LLT = LLT0.copy()
+    mu = np.zeros(n)
+    tau, v = np.zeros(n), np.zeros(n)
+    tau_cav, v_cav = np.zeros(n), np.zeros(n)
+    Z_hat, mu_hat, s2_hat = np.zeros(n), np.zeros(n), np.zeros(n)
+    tau_old = v_old = None
+    it = 0
+    stop = False
+    while not stop and it < max_iters:
+        for i in order_fn(n):
+            tau_cav[i] = 1.0 / Sigma_diag[i] - eta * tau[i]
+            v_cav[i] = mu[i] / Sigma_diag[i] - eta * v[i]
+            Z_hat[i], mu_hat[i], s2_hat[i] = bernoulli_moments_match_ep(y[i], tau_cav[i], v_cav[i])
+            d_tau = delta / eta * (1.0 / s2_hat[i] - 1.0 / Sigma_diag[i])
+            d_v = delta / eta * (mu_hat[i] / s2_hat[i] - mu[i] / Sigma_diag[i])
+            prev = tau[i]
+            tau[i] += d_tau
+            if tau[i] < _EPS:
+                tau[i] = _EPS
+                d_tau = tau[i] - prev
+            v[i] += d_v
+            # posteriorParamsDTC._update_rank1
+            k = Kmn[:, i].copy()
+            LLT += d_tau * np.outer(k, k)
+            L = jitchol(LLT)
+            V = dtrtrs(L, Kmn, lower=1)
+            Sigma_diag = np.maximum(np.sum(V * V, 0), _EPS)
+            si = np.dot(V.T, V[:, i])
+            mu = mu + (d_v - d_tau * mu[i]) * si
+        mu, Sigma_diag, LLT = epdtc_recompute(LLT0, Kmn, tau, v)
+        Sigma_diag = np.maximum(Sigma_diag, _EPS)
+        if it > 0:
+            stop = (np.mean(np.square(tau - tau_old)) < epsilon) and (np.mean(np.square(v - v_old)) < epsilon)
+        tau_old, v_old = tau.copy(), v.copy()
+        it += 1
+    log_Z_tilde = np.sum(np.log(Z_hat) + 0.5 * LOG_2_PI + 0.5 * np.log(1.0 + tau / tau_cav)
+                         - 0.5 * (v ** 2) / (tau_cav + tau)
+                         + 0.5 * (v_cav * ((tau / tau_cav) * v_cav - 2.0 * v) / (tau_cav + tau)))
+    return dict(tau=tau, v=v, tau_cav=tau_cav, v_cav=v_cav, Z_hat=Z_hat, mu_hat=mu_hat, sigma2_hat=s2_hat,
+                log_Z_tilde=float(log_Z_tilde), sweeps=it, mu=mu, Sigma_diag=Sigma_diag)
+
+
+def epdtc_inference(kern, X, Z, sites):
+    """EPDTC.inference for FIXED sites (ep_mode "alternated": every objective evaluation of one optimize() call):
+    VarDTC.inference(Y = v / tau, precision = tau, Lm = jitchol(K(Z)), Z_tilde = log Z_tilde)."""
+    kern = as_add(kern)
+    tau, v = sites["tau"], sites["v"]
+    num_data, num_inducing, output_dim = X.shape[0], Z.shape[0], 1
+    Y = (v / tau)[:, None]
+    precision = tau[:, None]
+    VVT_factor = precision * Y
+    Lm = jitchol(kern.K(Z))
+    Kmm = tdot(Lm)
+    psi0 = kern.Kdiag(X)
+    psi1 = kern.K(X, Z)
+    tmp = psi1 * np.sqrt(precision)
+    tmp = dtrtrs(Lm, tmp.T, lower=1)
+    A = tdot(tmp)
+    B = np.eye(num_inducing) + A
+    LB = jitchol(B)
+    psi1Vf = np.dot(psi1.T, VVT_factor)
+    tmp = dtrtrs(Lm, psi1Vf, lower=1, trans=0)
+    _LBi_Lmi_psi1Vf = dtrtrs(LB, tmp, lower=1, trans=0)
+    tmp = dtrtrs(LB, _LBi_Lmi_psi1Vf, lower=1, trans=1)
+    Cpsi1Vf = dtrtrs(Lm, tmp, lower=1, trans=1)
+    delit = tdot(_LBi_Lmi_psi1Vf)
+    data_fit = np.trace(delit)
+    DBi_plus_BiPBi = backsub_both_sides(LB, output_dim * np.eye(num_inducing) + delit)
+    delit = -0.5 * DBi_plus_BiPBi
+    delit += -0.5 * B * output_dim
+    delit += output_dim * np.eye(num_inducing)
+    dL_dKmm = backsub_both_sides(Lm, delit)
+    # _compute_dL_dpsi, het_noise and certain inputs
+    dL_dpsi0 = -0.5 * output_dim * (precision * np.ones([num_data, 1])).flatten()
+    dL_dpsi1 = np.dot(VVT_factor, Cpsi1Vf.T)
+    dL_dpsi2_beta = 0.5 * backsub_both_sides(Lm, output_dim * np.eye(num_inducing) - DBi_plus_BiPBi)
+    dL_dpsi1 += 2.0 * np.dot(dL_dpsi2_beta, (psi1 * precision).T).T
+    # _compute_log_marginal_likelihood, het_noise
+    beta = precision
+    lik_1 = (-0.5 * num_data * output_dim * LOG_2_PI + 0.5 * output_dim * np.sum(np.log(beta))
+             - 0.5 * np.sum(beta.ravel() * np.square(Y).sum(axis=-1)))
+    lik_2 = -0.5 * output_dim * (np.sum(beta.flatten() * psi0) - np.trace(A))
+    lik_3 = -output_dim * (np.sum(np.log(np.diag(LB))))
+    lik_4 = 0.5 * data_fit
+    log_marginal = lik_1 + lik_2 + lik_3 + lik_4 + sites["log_Z_tilde"]
+    Bi = -dpotri(LB, lower=1)
+    Bi[np.diag_indices_from(Bi)] += 1.0
+    woodbury_inv = backsub_both_sides(Lm, Bi)
+    return dict(log_marginal=float(log_marginal), woodbury_vector=Cpsi1Vf, woodbury_inv=woodbury_inv, Lm=Lm, LB=LB,
+                A=A, Kmm=Kmm, psi1=psi1, dL_dKmm=dL_dKmm, dL_dKnm=dL_dpsi1, dL_dKdiag=dL_dpsi0, dL_dthetaL=0.0,
+                data_fit=data_fit)
+
+
 def bernoulli_predictive_mean(mu, var):
     """Bernoulli.predictive_mean with the probit link: Phi(mu / sqrt(1 + var))  (GP.predict of a classifier,
     gp_model/base.py:187 -> classification.py:83,99)."""

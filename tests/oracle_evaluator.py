@@ -43,6 +43,9 @@ class OracleEvaluator:
     def _post(self, model):
         k = self._kern(model)
         if getattr(model, "is_classifier", False):
+            if model.is_sparse:
+                inf = go.epdtc_inference(k, model.X, model.Z, self._ensure_sites(model))
+                return k, model.Z, inf["woodbury_vector"], inf["woodbury_inv"]
             inf = go.ep_inference(k, model.X, self._ensure_sites(model))
             return k, model.X, inf["woodbury_vector"], inf["woodbury_inv"]
         if model.is_sparse:
@@ -68,16 +71,27 @@ class OracleEvaluator:
     def _ensure_sites(self, model):
         if model._sites is None:
             k = self._kern(model)
-            sites = go.expectation_propagation(k.K(model.X), model.Y[:, 0], epsilon=model.ep_epsilon, eta=model.ep_eta,
-                                               delta=model.ep_delta)
+            if model.is_sparse:
+                sites = go.expectation_propagation_dtc(k.K(model.Z), k.K(model.Z, model.X), model.Y[:, 0],
+                                                       epsilon=model.ep_epsilon, eta=model.ep_eta, delta=model.ep_delta)
+            else:
+                sites = go.expectation_propagation(k.K(model.X), model.Y[:, 0], epsilon=model.ep_epsilon,
+                                                   eta=model.ep_eta, delta=model.ep_delta)
             model._set_sites(sites["tau"], sites["v"], sites["log_Z_tilde"], sites["sweeps"])
         return dict(tau=model._sites[0], v=model._sites[1], log_Z_tilde=model._sites[2])
 
     def ep_lml(self, model):
+        if model.is_sparse:
+            return go.epdtc_inference(self._kern(model), model.X, model.Z, self._ensure_sites(model))["log_marginal"]
         return go.ep_inference(self._kern(model), model.X, self._ensure_sites(model))["log_marginal"]
 
     def ep_lml_grad(self, model):
         k = self._kern(model)
+        if model.is_sparse:
+            inf = go.epdtc_inference(k, model.X, model.Z, self._ensure_sites(model))
+            kg, _, dZ = go.sparse_gradients(k, model.X, model.Z, inf)
+            dvar, dlen = self._expand(k, kg)
+            return inf["log_marginal"], dvar, dlen, dZ
         inf = go.ep_inference(k, model.X, self._ensure_sites(model))
         dvar, dlen = self._expand(k, k.param_gradients_full(inf["dL_dK"], model.X, None))
-        return inf["log_marginal"], dvar, dlen
+        return inf["log_marginal"], dvar, dlen, None

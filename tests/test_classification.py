@@ -87,10 +87,78 @@ def test_classifier_host_logic_on_oracle_evaluator(monkeypatch, tmp_path):
     clf2 = GaussianProcessClassifier()
     clf2.load(str(tmp_path / "clf"))
     assert np.allclose(clf2.predict_proba(X[:20]), clf.predict_proba(X[:20]), atol=1e-12)
-    with pytest.raises(NotImplementedError):
-        SparseGaussianProcessClassifier().fit(X, y)
     with pytest.raises(ValueError):
         GaussianProcessClassifier().fit(X, y + 2.0)
+
+
+def test_oracle_epdtc_fixed_point_and_gradients():
+    """EPDTC restatement: EP's fixed point holds on the DTC posterior (the Gaussian marginals the VarDTC posterior
+    predicts at the training rows are the ones the site updates tracked, and they match the tilted moments), the
+    gradients of the fixed-site bound w.r.t. kernel parameters and Z agree with central differences, and with
+    Z = X the inducing-point posterior is the dense one: the sites of the dense EP are a fixed point of EPDTC too."""
+    X, y = _data(220, 2, 4)
+    rng = np.random.default_rng(0)
+    Z = X[rng.permutation(220)[:25]].copy()
+    kw = dict(variance=1.3, lengthscale=0.9)
+    kern = go.make_kernel(["RBF"], 2, [kw])
+    sites = go.expectation_propagation_dtc(kern.K(Z), kern.K(Z, X), y, order_fn=_Orders(1))
+    assert 2 <= sites["sweeps"] <= 30 and np.all(sites["tau"] > 0)
+    inf = go.epdtc_inference(kern, X, Z, sites)
+    mu, var = go.raw_predict(kern, X, Z, inf["woodbury_vector"], inf["woodbury_inv"])
+    Qnn = np.sum(go.dtrtrs(inf["Lm"], kern.K(Z, X), lower=1) ** 2, 0)
+    # the VarDTC posterior at the training rows = EP's (mu, Sigma_diag) + the DTC residual Knn - Qnn
+    assert np.abs(mu[:, 0] - sites["mu"]).max() < 1e-10
+    assert np.abs(var[:, 0] - (kern.Kdiag(X) - Qnn + sites["Sigma_diag"])).max() < 1e-10
+    assert np.abs(sites["mu"] - sites["mu_hat"]).max() < 5e-3
+    assert np.abs(sites["Sigma_diag"] - sites["sigma2_hat"]).max() < 5e-3
+    kg, _, dZ = go.sparse_gradients(kern, X, Z, inf)
+
+    def lml(var_=1.3, ls_=0.9, Z_=Z):
+        return go.epdtc_inference(go.make_kernel(["RBF"], 2, [dict(variance=var_, lengthscale=ls_)]), X, Z_, sites)["log_marginal"]
+    e = 1e-6
+    assert abs((lml(var_=1.3 + e) - lml(var_=1.3 - e)) / (2 * e) - kg[0][0]) <= 1e-6 * max(1.0, abs(kg[0][0]))
+    assert abs((lml(ls_=0.9 + e) - lml(ls_=0.9 - e)) / (2 * e) - kg[0][1][0]) <= 1e-6 * max(1.0, abs(kg[0][1][0]))
+    for (m, q) in ((0, 0), (7, 1), (24, 0)):
+        Zp, Zm = Z.copy(), Z.copy()
+        Zp[m, q] += e; Zm[m, q] -= e
+        assert abs((lml(Z_=Zp) - lml(Z_=Zm)) / (2 * e) - dZ[m, q]) <= 1e-5 * max(1.0, np.abs(dZ).max())
+    # Z = X: Qnn = Knn, and one more EPDTC sweep from the dense sites leaves them where they are
+    Xs, ys = X[:60], y[:60]
+    dense = go.expectation_propagation(kern.K(Xs), ys, order_fn=_Orders(2), epsilon=1e-12)
+    sp = go.expectation_propagation_dtc(kern.K(Xs), kern.K(Xs), ys, order_fn=_Orders(2), epsilon=1e-12)
+    assert np.abs(sp["tau"] - dense["tau"]).max() <= 1e-4 * dense["tau"].max()
+    assert np.abs(sp["v"] - dense["v"]).max() <= 1e-4 * np.abs(dense["v"]).max()
+
+
+def test_sparse_classifier_host_logic_on_oracle_evaluator(monkeypatch, tmp_path):
+    from edrgp_amd import models
+    from edrgp_amd.gp_model import SparseGaussianProcessClassifier
+    monkeypatch.setattr(models, "HipEvaluator", lambda device=None: OracleEvaluator())
+    X, y = _data(160, 3, 6)
+    np.random.seed(4)
+    clf = SparseGaussianProcessClassifier(kernels="RBF", num_inducing=12)
+    clf.fit(X, y, max_iters=10)
+    m = clf.estimator_
+    assert m.Z.shape == (12, 3) and m.is_sparse and m.is_classifier
+    assert m.parameter_names() == ["inducing_inputs"] * 36 + ["rbf.variance", "rbf.lengthscale"]
+    assert m.ep_sweeps >= 2 and m._sites is not None
+    proba = clf.predict_proba(X)
+    assert proba.shape == (160,) and np.all((proba > 0) & (proba < 1))
+    assert np.mean(clf.predict(X) == (y == 1)) > 0.8
+    assert clf.predict_gradient(X[:7]).shape == (7, 3)
+    x0 = m.optimizer_array.copy()
+    f0, g0 = m._objective_grads(x0)
+    for i in (0, 5, 17, 35, 36, 37):
+        e = np.zeros_like(x0); e[i] = 1e-6
+        fd = (m._objective_grads(x0 + e)[0] - m._objective_grads(x0 - e)[0]) / 2e-6
+        assert abs(fd - g0[i]) <= 1e-4 * max(1.0, abs(g0[i]))
+    m.optimizer_array = x0
+    clf.save(str(tmp_path / "sclf"))
+    clf2 = SparseGaussianProcessClassifier()
+    clf2.load(str(tmp_path / "sclf"))
+    assert np.allclose(clf2.predict_proba(X[:20]), clf.predict_proba(X[:20]), atol=1e-12)
+    with pytest.raises(NotImplementedError):
+        SparseGaussianProcessClassifier(likelihood="other").fit(X, y)
 
 
 @pytest.mark.gpu
@@ -201,3 +269,134 @@ def test_device_ep_fixed_point_beyond_oracle_sizes(hip):
             vals.append(hip.ep_lml())
         fd = (vals[0] - vals[1]) / (2 * e)
         assert abs(fd - an) <= 1e-5 * max(1.0, abs(an)), (name, fd, an)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,D,M,kind", [(150, 2, 10, "RBF"), (600, 5, 40, "Matern52"), (900, 3, 130, "RBF"),
+                                        (400, 4, 30, "RBF+Matern32")])
+def test_device_epdtc_matches_oracle(hip, N, D, M, kind):
+    """EPDTC on the device (rank-one updates of B^-1 in the whitened basis) against the oracle's restatement of
+    upstream's per-site refactorisation, for the SAME site orders: sweeps, sites, log Z_tilde; then the fixed-site
+    bound, its gradients (kernel parameters and Z) and the posterior at other hyper-parameters."""
+    X, y = _data(N, D, N + M)
+    kinds = kind.split("+")
+    rng = np.random.default_rng(M)
+    Z = X[rng.permutation(N)[:M]].copy()
+
+    def kern_of(scale):
+        opts = [dict(variance=1.2 * scale / (i + 1), lengthscale=(0.8 + 0.3 * i) * np.sqrt(D) * scale) for i in range(len(kinds))]
+        return go.make_kernel(kinds, D, opts), [o["variance"] for o in opts], np.array([[o["lengthscale"]] * D for o in opts])
+
+    kern, var, ls = kern_of(1.0)
+    orders = _Orders(7)
+    sites = go.expectation_propagation_dtc(kern.K(Z), kern.K(Z, X), y, order_fn=orders)
+    hip.set_data(X, y)
+    hip.set_inducing(Z)
+    hip.set_kernel(kinds, var, ls, 1.0)
+    hip.epdtc_begin(y)
+    sweeps, stop = 0, False
+    while not stop:
+        d_tau, d_v = hip.epdtc_sweep(orders.used[sweeps])
+        if sweeps > 0:
+            stop = d_tau < 1e-6 and d_v < 1e-6
+        sweeps += 1
+        assert sweeps <= len(orders.used)
+    assert sweeps == sites["sweeps"]
+    logZt = hip.ep_finish()
+    tau, v = hip.ep_get_sites()
+    assert np.abs(tau - sites["tau"]).max() <= 1e-7 * np.abs(sites["tau"]).max()
+    assert np.abs(v - sites["v"]).max() <= 1e-7 * np.abs(sites["v"]).max()
+    assert abs(logZt - sites["log_Z_tilde"]) <= 1e-8 * max(abs(sites["log_Z_tilde"]), float(N))
+    # fixed sites, other hyper-parameters and inducing inputs (what the optimiser does)
+    kern2, var2, ls2 = kern_of(1.15)
+    Z2 = Z + 0.05 * rng.standard_normal(Z.shape)
+    dev_sites = dict(tau=tau, v=v, log_Z_tilde=logZt)
+    inf = go.epdtc_inference(kern2, X, Z2, dev_sites)
+    hip.set_inducing(Z2)
+    hip.set_kernel(kinds, var2, ls2, 1.0)
+    lml, dvar, dlen, dZ = hip.epdtc_lml_grad()
+    assert abs(lml - inf["log_marginal"]) <= 1e-9 * max(abs(inf["log_marginal"]), float(N))
+    assert abs(hip.epdtc_lml() - lml) <= 1e-12 * abs(lml)
+    kg, _, dZ_ref = go.sparse_gradients(kern2, X, Z2, inf)
+    gs = max(max(abs(g[0]), abs(g[1][0])) for g in kg)
+    for p, g in enumerate(kg):
+        assert abs(dvar[p] - g[0]) <= 1e-7 * gs and abs(dlen[p].sum() - g[1][0]) <= 1e-7 * gs
+    assert np.abs(dZ - dZ_ref).max() <= 1e-7 * max(1.0, np.abs(dZ_ref).max())
+    hip.epdtc_posterior()
+    Xs = np.vstack([np.random.default_rng(1).standard_normal((40, D)), X[:8]])
+    mu_ref, var_ref = go.raw_predict(kern2, Xs, Z2, inf["woodbury_vector"], inf["woodbury_inv"])
+    mu, vr = hip.predict(Xs)
+    assert np.abs(mu - mu_ref[:, 0]).max() <= 1e-8 * max(1.0, np.abs(mu_ref).max())
+    assert np.abs(vr - var_ref[:, 0]).max() <= 1e-8 * max(1.0, np.abs(var_ref).max())
+    jac_ref = go.predictive_gradients_mean(kern2, Xs, Z2, inf["woodbury_vector"])[:, :, 0]
+    assert np.abs(hip.predict_grad(Xs) - jac_ref).max() <= 1e-8 * max(1.0, np.abs(jac_ref).max())
+
+
+@pytest.mark.gpu
+def test_sparse_classifier_estimator_and_edr_end_to_end():
+    from edrgp_amd import EffectiveDimensionalityReduction
+    from edrgp_amd.gp_model import SparseGaussianProcessClassifier
+    from edrgp_amd.utils import SVDTransformer
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((800, 4))
+    w = np.array([0.8, -0.6, 0.0, 0.0])
+    y = ((X @ w) + 0.2 * rng.standard_normal(800) > 0).astype(float)
+    np.random.seed(0)
+    clf = SparseGaussianProcessClassifier(kernels="RBF", kernel_options={"ARD": True}, num_inducing=30).fit(X, y, max_iters=60)
+    assert np.mean(clf.predict(X) == (y == 1)) > 0.9
+    p = clf.predict_proba(X)
+    assert np.all((p > 0) & (p < 1))
+    m = clf.estimator_
+    assert m.ep_sweeps >= 2 and m.Z.shape == (30, 4)
+    # the optimiser-space gradient of the device objective against its own central differences (sites fixed)
+    x0 = m.optimizer_array.copy()
+    f0, g0 = m._objective_grads(x0)
+    for i in (0, 41, 119, 120, 122):
+        e = np.zeros_like(x0); e[i] = 1e-5
+        fd = (m._objective_grads(x0 + e)[0] - m._objective_grads(x0 - e)[0]) / 2e-5
+        assert abs(fd - g0[i]) <= 1e-4 * max(1.0, np.abs(g0).max())
+    m.optimizer_array = x0
+    np.random.seed(1)
+    edr = EffectiveDimensionalityReduction(SparseGaussianProcessClassifier(num_inducing=30), SVDTransformer(), n_components=1,
+                                           normalize=True)
+    edr.fit(X, y, max_iters=40)
+    c = edr.components_[0] / np.linalg.norm(edr.components_[0])
+    assert abs(c @ w) > 0.95
+
+
+@pytest.mark.gpu
+def test_device_epdtc_fixed_point_beyond_oracle_sizes(hip):
+    """N = 20000, M = 256 (the oracle refactors an M x M matrix and solves against K_mn per site: hours).  Properties:
+    convergence in a few sweeps; at the fixed point the VarDTC posterior's marginals at the training rows, less the DTC
+    residual Knn - Qnn, match the tilted moments rebuilt on the host from the device's sites."""
+    import time
+    N, D, M = 20000, 4, 256
+    X, y = _data(N, D, 13)
+    rng = np.random.default_rng(2)
+    Z = X[rng.permutation(N)[:M]].copy()
+    var, ls = 1.0, 1.5
+    hip.set_data(X, y)
+    hip.set_inducing(Z)
+    hip.set_kernel(["RBF"], [var], np.full((1, D), ls), 1.0)
+    t0 = time.perf_counter()
+    hip.epdtc_begin(y)
+    sweeps, stop = 0, False
+    while not stop and sweeps < 40:
+        d_tau, d_v = hip.epdtc_sweep(rng.permutation(N))
+        stop = sweeps > 0 and d_tau < 1e-6 and d_v < 1e-6
+        sweeps += 1
+    hip.ep_finish()
+    print(f"EPDTC N={N} M={M}: {sweeps} sweeps in {time.perf_counter() - t0:.2f} s")
+    assert stop and sweeps <= 15
+    tau, v = hip.ep_get_sites()
+    assert np.all(tau > 0)
+    hip.epdtc_posterior()
+    mu, s2 = hip.predict(X)
+    kern = go.make_kernel(["RBF"], D, [dict(variance=var, lengthscale=ls)])
+    Lm = go.jitchol(kern.K(Z))
+    Qnn = np.sum(go.dtrtrs(Lm, kern.K(Z, X), lower=1) ** 2, 0)
+    sd = s2 - (var - Qnn)                                  # Sigma_diag of the DTC posterior EP worked on
+    tau_c, v_c = 1.0 / sd - tau, mu / sd - v
+    idx = rng.permutation(N)[:2000]
+    mom = np.array([go.bernoulli_moments_match_ep(y[i], tau_c[i], v_c[i]) for i in idx])
+    assert np.abs(mom[:, 1] - mu[idx]).max() < 5e-3 and np.abs(mom[:, 2] - sd[idx]).max() < 5e-3

@@ -242,8 +242,9 @@ def test_fit_gram_falls_back_on_rank_deficient_gradients():
     assert np.allclose(np.abs(a2.components_ @ b2.components_.T), np.eye(2), atol=1e-8)
 
 
-def test_sparse_classifier_refuses_at_fit():
+def test_sparse_classifier_is_clonable_and_refuses_other_likelihoods():
     from edrgp_amd.gp_model import SparseGaussianProcessClassifier
-    est = clone(SparseGaussianProcessClassifier(num_inducing=5))        # constructible and clonable ...
-    with pytest.raises(NotImplementedError):                            # ... and refused before any work
-        est.fit(np.zeros((4, 2)), np.array([0, 1, 0, 1]))
+    est = clone(SparseGaussianProcessClassifier(num_inducing=5, likelihood="Gaussian"))      # constructible and clonable
+    assert est.num_inducing == 5
+    with pytest.raises(NotImplementedError):                 # only GPy's default (Bernoulli, probit) is built
+        est.fit(np.random.default_rng(0).standard_normal((8, 2)), np.array([0, 1, 0, 1, 1, 0, 1, 0]))
