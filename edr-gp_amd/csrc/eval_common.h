@@ -112,6 +112,8 @@ inline double var_sum(const Ctx* c) {
 }
 
 int ensure_mats(Ctx* c, int n, int count);
+// W = K Li^T and b = W^T y of the stable form (sparse_eval.hip)
+int stable_product(Ctx* c, const double* K, int64_t rows, int M, const double* Li, const double* y, double* W, double* b);
 int dense_kernel_gradients(Ctx* c, const double* dK, double* Tn, std::vector<double>* dvar, std::vector<double>* dlen);
 
 // jitchol's jitter ladder: level -1 = none, level k = mean(diag) * 1e-6 * 10^k

@@ -38,6 +38,28 @@ int ensure_mats(Ctx* c, int n, int count) {
     return EDRGP_OK;
 }
 
+// The stable form's product W = K Li^T (rows x M; Li lower triangular: column tile j has a k-range of j + 1 tiles) with
+// b = W^T y out of the same launch's epilogue (per-row-tile partials, summed in a fixed order).  Shared by the
+// evaluation and the batched sweep.  (Measured: it runs at the Phi kernel's rate for this M once the tile-granular
+// k-ranges are counted -- 1.125 N M^2 flops at M = 1024, 59 vs 61 TFLOP/s; giving the rows of the last, partly
+// filled round of its persistent grid to small tiles instead changed nothing, 4.55 -> 4.52 ms at C2.)
+int stable_product(Ctx* c, const double* K, int64_t rows, int M, const double* Li, const double* y, double* W, double* b) {
+    if (rows < 128 || M < 128) {
+        TRY(gemm(c, false, true, (int)rows, M, M, 1.0, K, M, Li, M, 0.0, W, M, kopt(K_LE_COL, 0, 2)));
+        return gemv_t(c, (int)rows, M, 1.0, W, M, y, b);
+    }
+    const int tiles_m = (int)((rows + 127) / 128);
+    TRY(c->bpart.reserve((size_t)tiles_m * M * sizeof(double)));
+    FuseK fk{};
+    fk.y = y;
+    fk.bpart = c->bpart.d();
+    GemmOpts ow = kopt(K_LE_COL, 0, 4);
+    ow.force_tile = 128;
+    ow.fusek = &fk;
+    TRY(gemm(c, false, true, (int)rows, M, M, 1.0, K, M, Li, M, 0.0, W, M, ow));
+    return col_reduce(c, c->bpart.d(), tiles_m, M, b);
+}
+
 namespace {
 
 // globals over ranks (N, yy) -- data-dependent only, cached
@@ -302,23 +324,8 @@ struct SparseEval {
             const double* S = c->Knm.d();
             if (stable_form) {
                 ProfScope ps(c, EDRGP_PROF_GRADGEMM);
-                // W = K_nm Li^T with b = W^T y out of the same launch's epilogue (per-row-tile partials, fixed order)
-                const int tiles_m = (int)((rows + 127) / 128);
-                TRY(c->bpart.reserve((size_t)tiles_m * M * sizeof(double)));
-                FuseK fk{};
-                fk.y = c->y.d() + r0;
-                fk.bpart = c->bpart.d();
-                GemmOpts ow = kopt(K_LE_COL, 0, 4);
-                ow.force_tile = 128;
-                ow.fusek = &fk;
-                if (rows >= 128 && M >= 128) {
-                    TRY(gemm(c, false, true, (int)rows, M, M, 1.0, c->Knm.d(), M, Li, M, 0.0, c->W.d(), M, ow));
-                    TRY(col_reduce(c, c->bpart.d(), tiles_m, M, btarget));
-                } else {
-                    TRY(gemm(c, false, true, (int)rows, M, M, 1.0, c->Knm.d(), M, Li, M, 0.0, c->W.d(), M,
-                             kopt(K_LE_COL, 0, 2)));
-                    TRY(gemv_t(c, (int)rows, M, 1.0, c->W.d(), M, c->y.d() + r0, btarget));
-                }
+                // W = K_nm Li^T with b = W^T y out of the same pass (per-row-tile partials, fixed order)
+                TRY(stable_product(c, c->Knm.d(), rows, M, Li, c->y.d() + r0, c->W.d(), btarget));
                 S = c->W.d();
             }
             if (ch > 0) TRY(vec_axpy(c, M, 1.0, v_tmp, bvec));

@@ -228,21 +228,7 @@ int sweep_scales(Ctx* c, int G, const double* ls, double var, double noise_var, 
             // W = K_g Lm_g^-T with b = W^T y out of the same launch (sparse_eval.hip, phase 2)
             ProfScope ps(c, EDRGP_PROF_GRADGEMM);
             TRY(c->W.reserve((size_t)(N + 16) * M * sizeof(double)));
-            const int tiles_m = (int)((N + 127) / 128);
-            TRY(c->bpart.reserve((size_t)tiles_m * M * sizeof(double)));
-            FuseK fk{};
-            fk.y = c->y.d();
-            fk.bpart = c->bpart.d();
-            GemmOpts ow = kopt(K_LE_COL, 0, 4);
-            ow.force_tile = 128;
-            ow.fusek = &fk;
-            if (M >= 128) {
-                TRY(gemm(c, false, true, (int)N, M, M, 1.0, Kg, M, Li + (size_t)g * MM, M, 0.0, c->W.d(), M, ow));
-                TRY(col_reduce(c, c->bpart.d(), tiles_m, M, bvec));
-            } else {
-                TRY(gemm(c, false, true, (int)N, M, M, 1.0, Kg, M, Li + (size_t)g * MM, M, 0.0, c->W.d(), M, kopt(K_LE_COL, 0, 2)));
-                TRY(gemv_t(c, (int)N, M, 1.0, c->W.d(), M, c->y.d(), bvec));
-            }
+            TRY(stable_product(c, Kg, N, M, Li + (size_t)g * MM, c->y.d(), c->W.d(), bvec));
             S = c->W.d();
         }
         if (Npad > N) HIP_TRY(hipMemsetAsync(const_cast<double*>(S) + (size_t)N * M, 0, (size_t)(Npad - N) * M * sizeof(double), c->stream));
