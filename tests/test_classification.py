@@ -273,7 +273,7 @@ def test_device_ep_fixed_point_beyond_oracle_sizes(hip):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,D,M,kind", [(150, 2, 10, "RBF"), (600, 5, 40, "Matern52"), (900, 3, 130, "RBF"),
-                                        (400, 4, 30, "RBF+Matern32")])
+                                        (400, 4, 30, "RBF+Matern32"), (70, 2, 1, "RBF"), (90, 3, 3, "Matern32")])
 def test_device_epdtc_matches_oracle(hip, N, D, M, kind):
     """EPDTC on the device (rank-one updates of B^-1 in the whitened basis) against the oracle's restatement of
     upstream's per-site refactorisation, for the SAME site orders: sweeps, sites, log Z_tilde; then the fixed-site
