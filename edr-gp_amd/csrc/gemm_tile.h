@@ -139,10 +139,12 @@ struct TileLoaderT {
 
 // What the k-loop of a kernel instance looks like: the fragment pipeline (fragments of k-step kk + 1 read while the
 // MFMAs of step kk issue, PIPE_M MFMAs between two LDS reads), the k-step after whose MFMAs the next tile's registers
-// go to LDS, and which operand images are read through volatile pointers.
-template <bool FRAG_PIPE_, int PIPE_M_, bool EARLY_STORE_, int EARLY_KK_, bool VOL_A_, bool VOL_B_>
+// go to LDS, which operand images are read through volatile pointers, and whether the interior and the guarded loader get
+// a k-loop each (UNSWITCH) or share one with the choice inside it.
+template <bool FRAG_PIPE_, int PIPE_M_, bool EARLY_STORE_, int EARLY_KK_, bool VOL_A_, bool VOL_B_, bool UNSWITCH_ = false>
 struct GemmLoopCfg {
     static constexpr bool FRAG_PIPE = FRAG_PIPE_, EARLY_STORE = EARLY_STORE_, VOL_A = VOL_A_, VOL_B = VOL_B_;
+    static constexpr bool UNSWITCH = UNSWITCH_;
     static constexpr int PIPE_M = PIPE_M_, EARLY_KK = EARLY_KK_;
 };
 
@@ -151,12 +153,22 @@ struct GemmLoopCfg {
 // global -> registers during the MFMAs of tile t and written to the free LDS buffer in the middle of the MFMA phase; one
 // barrier per k-tile.  `prio`: the short staging / barrier phases run at raised priority so the partner wave's MFMA
 // stream cannot starve them.  (m0l, n0l): where the operand tiles are actually read (timing probes alias them).
-template <typename T, int BM, int BN, bool AKM, bool BKM, typename Cfg>
-__device__ __forceinline__ void gemm_mainloop(typename GemmScalar<T>::acc_t (&acc)[BM / 32][BN / 32], const T* __restrict__ A,
-                                              const T* __restrict__ B, int lda, int ldb, int m0, int n0, int m0l, int n0l,
-                                              int Mlim, int Nlim, int Klim, int kt0, int kt1, bool vA, bool vB,
-                                              T (*As)[TileLoaderT<T, BM, AKM>::SIZE], T (*Bs)[TileLoaderT<T, BN, BKM>::SIZE],
-                                              int tid, int wm, int wn, int lr, int lq, bool prio) {
+// The k-loop for one loader kind -- interior workgroup (full tile, full k-tiles, 16-byte aligned rows, 32-bit tile
+// footprint: NV 16-byte loads per operand and k-tile, nothing else) or the guarded loader -- or, SPLIT = false, for
+// both with the choice (`fast`) made inside the loop.  Which of the two forms a kernel takes is a measured choice
+// (Cfg::UNSWITCH), because the two compile to different schedules and address forms (a loop per kind: wave-uniform base
+// in an SGPR pair + 32-bit lane offsets; one loop: per-lane 64-bit addresses and a branch per k-tile):
+//   Phi (same box, Cm):            a loop per kind 8.58 ms per bound evaluation, L2 hit rate 72 %; one loop 8.63 ms, 54 %
+//   gradient contraction (Cm):     a loop per kind 22.38 ms per bound+gradient evaluation; one loop 22.08 ms
+// (the hit rate: the co-running workgroups of an XCD share their K_nm rows in its L2 only while they walk them within
+// ~16 k-tiles of each other, which the schedule influences; TCC_HIT / TCC_MISS of the Phi launch alone,
+// tools/tcc_libs.sh -- neither kernel is bound by the fabric, 1-2 TB/s).
+template <typename T, int BM, int BN, bool AKM, bool BKM, typename Cfg, bool SPLIT, bool FAST>
+__device__ __forceinline__ void gemm_kloop(typename GemmScalar<T>::acc_t (&acc)[BM / 32][BN / 32], const T* __restrict__ A,
+                                           const T* __restrict__ B, int lda, int ldb, int m0, int n0, int m0l, int n0l,
+                                           int Mlim, int Nlim, int Klim, int kt0, int kt1, bool vA, bool vB,
+                                           T (*As)[TileLoaderT<T, BM, AKM>::SIZE], T (*Bs)[TileLoaderT<T, BN, BKM>::SIZE],
+                                           int tid, int wm, int wn, int lr, int lq, bool prio, bool fast_rt) {
     typedef GemmScalar<T> S;
     typedef TileLoaderT<T, BM, AKM> LA;
     typedef TileLoaderT<T, BN, BKM> LB;
@@ -164,10 +176,7 @@ __device__ __forceinline__ void gemm_mainloop(typename GemmScalar<T>::acc_t (&ac
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
     LA la;
     LB lb;
-    // interior workgroup: full tile, full k-tiles, 16-byte aligned rows, 32-bit tile footprint
-    const bool fast = vA && vB && (m0 + BM <= Mlim) && (n0 + BN <= Nlim) && (kt1 * BK <= Klim) &&
-                      ((long long)LA::span_rows() * lda * (long long)sizeof(T) < (1LL << 31)) &&
-                      ((long long)LB::span_rows() * ldb * (long long)sizeof(T) < (1LL << 31));
+    const bool fast = SPLIT ? FAST : fast_rt;
     unsigned offA[LA::NV], offB[LB::NV];
     const char* baseA = reinterpret_cast<const char*>(A + LA::tile_origin(lda, m0l, kt0));
     const char* baseB = reinterpret_cast<const char*>(B + LB::tile_origin(ldb, n0l, kt0));
@@ -275,6 +284,30 @@ __device__ __forceinline__ void gemm_mainloop(typename GemmScalar<T>::acc_t (&ac
         }
         __syncthreads();
     }
+}
+
+template <typename T, int BM, int BN, bool AKM, bool BKM, typename Cfg>
+__device__ __forceinline__ void gemm_mainloop(typename GemmScalar<T>::acc_t (&acc)[BM / 32][BN / 32], const T* __restrict__ A,
+                                              const T* __restrict__ B, int lda, int ldb, int m0, int n0, int m0l, int n0l,
+                                              int Mlim, int Nlim, int Klim, int kt0, int kt1, bool vA, bool vB,
+                                              T (*As)[TileLoaderT<T, BM, AKM>::SIZE], T (*Bs)[TileLoaderT<T, BN, BKM>::SIZE],
+                                              int tid, int wm, int wn, int lr, int lq, bool prio) {
+    typedef TileLoaderT<T, BM, AKM> LA;
+    typedef TileLoaderT<T, BN, BKM> LB;
+    constexpr int BK = GemmScalar<T>::BK;
+    // interior workgroup: full tile, full k-tiles, 16-byte aligned rows, 32-bit tile footprint
+    const bool fast = vA && vB && (m0 + BM <= Mlim) && (n0 + BN <= Nlim) && (kt1 * BK <= Klim) &&
+                      ((long long)LA::span_rows() * lda * (long long)sizeof(T) < (1LL << 31)) &&
+                      ((long long)LB::span_rows() * ldb * (long long)sizeof(T) < (1LL << 31));
+    if (!Cfg::UNSWITCH)
+        gemm_kloop<T, BM, BN, AKM, BKM, Cfg, false, false>(acc, A, B, lda, ldb, m0, n0, m0l, n0l, Mlim, Nlim, Klim, kt0, kt1, vA,
+                                                           vB, As, Bs, tid, wm, wn, lr, lq, prio, fast);
+    else if (fast)
+        gemm_kloop<T, BM, BN, AKM, BKM, Cfg, true, true>(acc, A, B, lda, ldb, m0, n0, m0l, n0l, Mlim, Nlim, Klim, kt0, kt1, vA,
+                                                         vB, As, Bs, tid, wm, wn, lr, lq, prio, true);
+    else
+        gemm_kloop<T, BM, BN, AKM, BKM, Cfg, true, false>(acc, A, B, lda, ldb, m0, n0, m0l, n0l, Mlim, Nlim, Klim, kt0, kt1, vA,
+                                                          vB, As, Bs, tid, wm, wn, lr, lq, prio, false);
 }
 
 }  // namespace edrgp

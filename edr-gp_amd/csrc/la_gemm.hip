@@ -309,7 +309,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     constexpr bool FRAG_PIPE = (EDRGP_FRAG_PIPE != 0) && ((BM == 128 && BN == 128 && (TAG == 1 || (T25 && EDRGP_FRAG_PIPE >= 2))) ||
                                                            (EDRGP_FRAG_PIPE >= 3 && BM == 64 && BN == 64));
     // k-loop shape of this instance (gemm_tile.h); the next tile goes to LDS after k-step BK/4 - 2 of 4
-    typedef GemmLoopCfg<FRAG_PIPE, PIPE_M, EARLY_STORE, BK / 4 - 2, VOL_FRAG && !AKM, VOL_FRAG && !BKM> LoopCfg;
+    // (a k-loop per loader kind for Phi only: gemm_tile.h, gemm_kloop)
+    typedef GemmLoopCfg<FRAG_PIPE, PIPE_M, EARLY_STORE, BK / 4 - 2, VOL_FRAG && !AKM, VOL_FRAG && !BKM, TAG == 1> LoopCfg;
     typedef TileLoader<BM, AKM> LA;
     typedef TileLoader<BN, BKM> LB;
     __shared__ __attribute__((aligned(16))) double As[2][LA::SIZE];
