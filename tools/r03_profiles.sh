@@ -16,13 +16,15 @@ echo "stats done"
 P1="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"
 P2="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU"
 i=0
-for set in "$P1" "$P2" "FETCH_SIZE" "WRITE_SIZE"; do
+P5="TCC_HIT_sum TCC_MISS_sum"
+P6="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"
+for set in "$P1" "$P2" "FETCH_SIZE" "WRITE_SIZE" "$P5" "$P6"; do
   i=$((i+1))
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc$i -- python3 tools/eval_trace.py Cm grad 2 > $O/pmc$i.log 2>&1 || exit 3
   cp $(ls $O/pmc$i/*/*counter_collection.csv | head -1) $O/pmc$i.csv; rm -rf $O/pmc$i
 done
-python tools/pmc_to_json.py $O/r03_pmc_syrk.json "gemm_f64_kernel<128, 128, true, true, 1>" $O/pmc1.csv $O/pmc2.csv $O/pmc3.csv $O/pmc4.csv > /dev/null
-python tools/pmc_to_json.py $O/r03_pmc_gradgemm.json "gemm_f64_kernel<128, 128, false, true, 2>" $O/pmc1.csv $O/pmc2.csv $O/pmc3.csv $O/pmc4.csv > /dev/null
+python tools/pmc_to_json.py $O/r03_pmc_syrk.json "gemm_f64_kernel<128, 128, true, true, 1>" $O/pmc1.csv $O/pmc2.csv $O/pmc3.csv $O/pmc4.csv $O/pmc5.csv $O/pmc6.csv > /dev/null
+python tools/pmc_to_json.py $O/r03_pmc_gradgemm.json "gemm_f64_kernel<128, 128, false, true, 2>" $O/pmc1.csv $O/pmc2.csv $O/pmc3.csv $O/pmc4.csv $O/pmc5.csv $O/pmc6.csv > /dev/null
 rm -f $O/pmc?.csv
 echo "pmc done"
 tools/eval_timeline.sh r03/tl Cm > /dev/null 2>&1
