@@ -807,6 +807,7 @@ int edrgp_get(edrgp_ctx* ctx, int which, double* buf, int64_t cap) {
                 if ((int64_t)n > cap) { set_error("edrgp_get: buffer too small"); return EDRGP_ERR_INVALID; }
                 std::vector<float> tmp(n);
                 HIP_TRY(hipStreamSynchronize(c->stream));
+                if (c->stream2) HIP_TRY(hipStreamSynchronize(c->stream2));
                 HIP_TRY(hipMemcpy(tmp.data(), c->Knm32.p, n * sizeof(float), hipMemcpyDeviceToHost));
                 for (size_t i = 0; i < n; ++i) buf[i] = (double)tmp[i];
                 return EDRGP_OK;
@@ -827,7 +828,10 @@ int edrgp_get(edrgp_ctx* ctx, int which, double* buf, int64_t cap) {
     }
     if (!src) { set_error("edrgp_get: object %d not computed yet", which); return EDRGP_ERR_STATE; }
     if ((int64_t)n > cap) { set_error("edrgp_get: buffer too small (%lld < %zu)", (long long)cap, n); return EDRGP_ERR_INVALID; }
+    // both streams: some of these objects (Lm, Lm^-1, Kmm^-1 ...) are written on the side stream; every evaluation joins
+    // it into the main stream before it returns, the second wait makes this accessor independent of that
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->stream2) HIP_TRY(hipStreamSynchronize(c->stream2));
     if (rows2d > 0 && Mw != M)
         HIP_TRY(hipMemcpy2D(buf, M * sizeof(double), src, Mw * sizeof(double), M * sizeof(double), rows2d, hipMemcpyDeviceToHost));
     else

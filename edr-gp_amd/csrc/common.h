@@ -338,7 +338,7 @@ struct Ctx {
     DBuf slabs, bpart, scal, info, gt_nm, gt_mm, tmpvec[6], panel, trtri_ws, dinv, red, lbaug;
     DBuf pack;                        // lower triangle of Phi and b, packed for the all-reduce
     DBuf sw_small, sw_r2, sw_mats, sw_kall;   // batched length-scale sweep (sweep_eval.hip)
-    DBuf ep_K, ep_Sigma, ep_vec;      // EP classifier (ep_eval.hip): K, Sigma (N x N), site / cavity / moment vectors
+    DBuf ep_K, ep_Sigma, ep_vec;      // EP classifiers (ep_eval.hip): K, Sigma (N x N; EPDTC: K_nm, U = K_nm Lm^-T, N x M), site / cavity / moment vectors
     bool ep_begun = false, ep_valid = false;
     bool ep_sparse = false, ep_fresh = false;   // the EP run in progress is EPDTC's; no site of it has been updated yet
     double ep_logZt = 0.0;            // log Z_tilde of the fitted sites
