@@ -67,6 +67,29 @@ int Ctx::ensure_pinned(size_t doubles) {
     return EDRGP_OK;
 }
 
+// Rows of K_nm kept resident at a time.  An explicit "chunk_rows" is taken as given.  Automatic: ALL local rows when five
+// N x M fp64 work arrays (K_nm, h(r), K_nm Lm^-T, the gradient contraction's T, one spare) fit into half of the memory
+// this context can still get and N M stays below 2^31 elements -- one Phi launch per evaluation, K_nm (and h) stay
+// resident for the gradient pass and for predictions on the training rows (config 3 whole on one GPU, 1M x 2048:
+// bound+gradients 212 -> 201 ms, predict_gradient's Gram matrix 19.8 -> 9.6 ms) -- otherwise chunks of 131072 rows.
+int64_t Ctx::chunk_rows_for(int M) {
+    if (chunk_rows > 0) return chunk_rows;
+    if (auto_chunk_N == N && auto_chunk_M == M && auto_chunk > 0) return auto_chunk;
+    auto_chunk = 131072;
+    if (N > auto_chunk && M > 0) {
+        size_t free_b = 0, total_b = 0;
+        const size_t held = Knm.bytes + Hnm.bytes + W.bytes + T.bytes;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const double need = 5.0 * (double)N * M * sizeof(double);
+            if (need <= 0.5 * (double)(free_b + held) && (double)(N + 16) * M < 2147483648.0 - 16777216.0) auto_chunk = N;
+        }
+        (void)hipGetLastError();
+    }
+    auto_chunk_N = N;
+    auto_chunk_M = M;
+    return auto_chunk;
+}
+
 int Ctx::drain_events() {
     for (auto& pe : pending_events) {
         float ms = 0.f;
@@ -222,7 +245,7 @@ static int predict_rows(Ctx* c, const double* Xs_dev, int64_t Ns, double* mean_h
     const KSpec ks = make_kspec(c);
     const double* Pp = c->post_dense ? c->X.d() : c->Z.d();
     const double* Pt = c->post_dense ? c->Xt.d() : c->Zt.d();
-    int64_t chunk = std::max<int64_t>(64, std::min<int64_t>(c->chunk_rows, (int64_t)(1LL << 28) / std::max(1, Mp)));
+    int64_t chunk = std::max<int64_t>(64, std::min<int64_t>(c->chunk_rows_for(Mp), (int64_t)(1LL << 28) / std::max(1, Mp)));
     chunk = std::min<int64_t>(chunk, Ns);
     TRY(c->Knm.reserve((size_t)chunk * Mp * sizeof(double)));
     TRY(c->W.reserve((size_t)chunk * Mp * sizeof(double)));
@@ -397,7 +420,7 @@ int edrgp_set_option(edrgp_ctx* ctx, const char* key, double value) {
     if (!key) return EDRGP_ERR_INVALID;
     // The product's options (include/edrgp_hip.h documents each).  None of them changes WHAT is computed beyond the
     // documented numerical choices (statistics form, precision of the row pass).
-    if (!std::strcmp(key, "chunk_rows")) c->chunk_rows = std::max<int64_t>(64, (int64_t)value);
+    if (!std::strcmp(key, "chunk_rows")) c->chunk_rows = (value <= 0.0) ? 0 : std::max<int64_t>(64, (int64_t)value);
     else if (!std::strcmp(key, "stats_mode")) c->stats_mode = (int)value;          // 0 auto, 1 gram, 2 stable
     else if (!std::strcmp(key, "pivot_ratio_max")) c->pivot_ratio_max = value;
     else if (!std::strcmp(key, "overlap")) c->overlap = (int)value;
@@ -801,7 +824,7 @@ int edrgp_get(edrgp_ctx* ctx, int which, double* buf, int64_t cap) {
         case EDRGP_GET_WV: src = c->wv.d(); n = (size_t)c->P; break;
         case EDRGP_GET_WINV: src = c->winv.d(); n = (size_t)c->P * c->P; break;
         case EDRGP_GET_KNM:
-            rows2d = (size_t)std::min<int64_t>(c->N, c->chunk_rows);
+            rows2d = (size_t)std::min<int64_t>(c->N, c->chunk_rows_for(c->M_work > 0 ? c->M_work : c->M));
             n = rows2d * M;
             if (c->last_mode == 3) {          // fp32 row pass: widen the resident chunk
                 if ((int64_t)n > cap) { set_error("edrgp_get: buffer too small"); return EDRGP_ERR_INVALID; }

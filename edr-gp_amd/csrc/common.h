@@ -311,7 +311,10 @@ struct Ctx {
     bool phi32_bad = false;           // the guard rejected the fp32 Phi for the current data: use the fp64 row pass
 
     // options
-    int64_t chunk_rows = 131072;
+    int64_t chunk_rows = 0;           // rows of K_nm resident at a time; 0 = automatic (chunk_rows_for below)
+    int64_t auto_chunk = 0, auto_chunk_N = -1;    // the automatic choice and the (N, M) it was made for
+    int auto_chunk_M = -1;
+    int64_t chunk_rows_for(int M);    // api.hip
     int syrk_splits = 0;              // 0 = auto
     bool profile = false;
     int stats_mode = 0;               // 0 auto, 1 gram (Phi = K^T K), 2 stable (K Li^T first)

@@ -181,7 +181,7 @@ struct SparseEval {
         ks = make_kspec(c);
         TRY(get_globals(c, &gl));
         TRY(ensure_mats(c, M, need_grad ? 16 : (need_post ? 10 : 7)));
-        chunk = std::min<int64_t>(N, std::max<int64_t>(64, c->chunk_rows));
+        chunk = std::min<int64_t>(N, std::max<int64_t>(64, c->chunk_rows_for(M)));
         nchunks = (N + chunk - 1) / chunk;
         // 16 spare rows: the row count handed to the Phi kernel is rounded up to whole k-tiles with zero rows
         TRY(c->Knm.reserve((size_t)(chunk + 16) * M * sizeof(double)));

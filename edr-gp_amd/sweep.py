@@ -74,7 +74,7 @@ def _sweep_worker(h, close, X, y, Z_rows, projections, n_scales, kind, variance,
         if close:
             h.close()
         elif big:
-            h.set_option("chunk_rows", 131072)
+            h.set_option("chunk_rows", 0)
     return out
 
 

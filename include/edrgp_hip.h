@@ -84,7 +84,8 @@ int  edrgp_ctx_destroy(edrgp_ctx* ctx);
 int  edrgp_sync(edrgp_ctx* ctx);
 /* Options (twelve; every other key is EDRGP_ERR_INVALID in the product library -- A/B switches of settled design
  * decisions and timing probes exist in probe builds only, see edr-gp_amd/build.py and tools/README.md):
- *  "chunk_rows"       rows of K_nm resident at a time (default 131072)
+ *  "chunk_rows"       rows of K_nm resident at a time; 0 (default) = automatic: all local rows when five N x M fp64 work
+ *                     arrays fit into half of the free device memory (and N M < 2^31), else 131072
  *  "stats_mode"       form of the row statistics: 0 automatic (pivot-ratio rule), 1 Gram form Phi = K_mn K_nm,
  *                     2 stable form via K_nm Lm^-T (GPy's operation order)
  *  "pivot_ratio_max"  automatic mode takes the stable form when (max / min diag Lm)^2 exceeds this (default 120)

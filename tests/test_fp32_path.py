@@ -135,7 +135,7 @@ def test_fp32_chunked_rows_match_resident(hip):
             hip.set_kernel(["RBF"], [1.0], ls[None, :], 0.05)
             out.append(hip.sparse_lml_grad())
     finally:
-        hip.set_option("chunk_rows", 131072)
+        hip.set_option("chunk_rows", 0)
         hip.set_option("f32_phi", 0)
         hip.set_option("precision", 64)
     a, b = out

@@ -42,7 +42,7 @@ def test_full_size_properties(hip, name, N, M, D, kind):
         # (1) chunking invariance (ragged chunks)
         hip.set_option("chunk_rows", 30000)
         lml_c, dvar_c, dlen_c, dnoise_c, dZ_c = hip.sparse_lml_grad()
-        hip.set_option("chunk_rows", 131072)
+        hip.set_option("chunk_rows", 0)
         # (different summation order of Phi, amplified by cond(Kmm) ~ 1e4: a few 1e-11 observed)
         assert abs(lml_c - lml) <= 1e-9 * abs(lml)
         assert abs(dvar_c[0] - dvar[0]) <= 1e-7 * abs(dvar[0])
@@ -103,7 +103,7 @@ def test_full_size_properties(hip, name, N, M, D, kind):
         assert np.abs(hip.predict(X[rows], False)[0] - mean[rows]).max() <= 1e-10
     finally:
         hip.set_option("stats_mode", 0)
-        hip.set_option("chunk_rows", 131072)
+        hip.set_option("chunk_rows", 0)
 
 
 @pytest.mark.parametrize("name,N,M,D,kind", CONFIGS[:3], ids=[c[0] for c in CONFIGS[:3]])

@@ -50,7 +50,7 @@ def rel(a, b):
 def device_run(hip, X, y, Z, kind, ell, noise, precision, n_var):
     D = X.shape[1]
     hip.set_option("stats_mode", 0)
-    hip.set_option("chunk_rows", 131072)
+    hip.set_option("chunk_rows", 0)
     hip.set_option("precision", precision)
     hip.set_data(X, y)
     hip.set_inducing(Z)

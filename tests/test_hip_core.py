@@ -145,17 +145,49 @@ def test_sparse_chunked_rows_equal_unchunked(hip):
     hip.set_data(X, y)
     hip.set_inducing(Z)
     set_kernel(hip, kern, 0.03)
-    hip.set_option("chunk_rows", 131072)
+    hip.set_option("chunk_rows", 0)
     a = hip.sparse_lml_grad()
     hip.set_option("chunk_rows", 400)          # 4 ragged chunks
     b = hip.sparse_lml_grad()
-    hip.set_option("chunk_rows", 131072)
+    hip.set_option("chunk_rows", 0)
     inf, kg, dn, dZ = oracle_sparse(kern, X, y, Z, 0.03)
     ref = inf["log_marginal"][0, 0]
     for r in (a, b):
         assert abs(r[0] - ref) <= 1e-10 * abs(ref)
         assert abs(r[1][0] - kg[0][0]) <= 1e-7 * abs(kg[0][0])
         assert np.abs(r[4] - dZ).max() <= 1e-7 * np.abs(dZ).max()
+
+
+def test_automatic_chunking_keeps_all_rows_resident_when_they_fit(hip):
+    """N above the 131072-row chunk of the chunked path: the automatic choice ("chunk_rows" = 0, the default) keeps the
+    whole K_nm resident (one row pass, K_nm and h(r) reused by the gradient pass and by predictions on the training
+    rows) and gives the numbers of the explicitly chunked run."""
+    N, M, D = 300000, 256, 8
+    X, y, Z = go.synthetic_problem(N, D, M, seed=5)
+    hip.set_data(X, y)
+    hip.set_inducing(Z)
+    hip.set_kernel(["Matern32"], [1.1], np.full((1, D), 1.3 * np.sqrt(D)), 0.02)
+    out = {}
+    for chunk in (0, 131072):
+        hip.set_option("chunk_rows", chunk)
+        g = hip.sparse_lml_grad()
+        hip.sparse_posterior()
+        mu, jac = hip.predict_train(True, True)
+        if chunk == 0:                              # all N rows of K_nm are resident: a 131072-row buffer is refused
+            from edrgp_amd._lib import EdrgpError
+            with pytest.raises(EdrgpError):
+                hip.get("KNM", (131072, M))
+            hip.get("KNM", (N, M))
+        else:
+            hip.get("KNM", (131072, M))
+        out[chunk] = (g, mu, jac)
+    hip.set_option("chunk_rows", 0)
+    a, b = out[0], out[131072]
+    assert abs(a[0][0] - b[0][0]) <= 1e-11 * abs(b[0][0])
+    assert np.abs(a[0][2] - b[0][2]).max() <= 1e-8 * np.abs(b[0][2]).max()
+    assert np.abs(a[0][4] - b[0][4]).max() <= 1e-8 * np.abs(b[0][4]).max()
+    assert np.abs(a[1] - b[1]).max() <= 1e-9 * max(1.0, np.abs(b[1]).max())
+    assert np.abs(a[2] - b[2]).max() <= 1e-8 * max(1.0, np.abs(b[2]).max())
 
 
 @pytest.mark.parametrize("N,M,D,mode", [(900, 65, 3, 0), (1500, 130, 6, 0), (2500, 192, 5, 2), (4000, 449, 9, 0)])
