@@ -9,6 +9,7 @@ for seed in (range(int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else
     print("seed", seed, "failing", bad, flush=True)
     tot += bad
 print("TOTAL failing:", len(tot))
-import fuzz_dense, fuzz_fp32
+import fuzz_dense, fuzz_fp32, fuzz_ep
 print("dense fuzz failing:", fuzz_dense.run(h, seed=11, n_cases=40, verbose=True))
 print("fp32 fuzz failing:", fuzz_fp32.run(h, seed=12, n_cases=40, verbose=True))
+print("EP / EPDTC fuzz failing:", fuzz_ep.run(h, seed=13, n_cases=60, verbose=True))
