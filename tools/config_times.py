@@ -8,13 +8,18 @@ from edrgp_amd.sweep import projection_sweep
 
 h = HipGP(0)
 
-def timeit(f, n=5):
-    for _ in range(6):          # warm-up incl. the one-time ~70 ms queue / allocation cost of a fresh process
+def timeit(f, n=9):
+    """Median of n calls after a warm-up (the one-time ~70 ms queue / allocation cost of a fresh process, clock ramp):
+    a mean over five calls once carried a single 60 ms hiccup of the box into the log as "C2 bound 17 ms"."""
+    for _ in range(6):
         f()
-    t0 = time.perf_counter()
+    ts = []
     for _ in range(n):
+        h.sync()
+        t0 = time.perf_counter()
         f()
-    return (time.perf_counter() - t0) / n * 1e3
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)) * 1e3
 
 for name, N, M, D, kind in [("C2", 100000, 1024, 16, "RBF"), ("Cm", 100000, 2048, 32, "RBF"),
                             ("C3 shard (1/8 of 1M rows)", 125000, 2048, 32, "Matern52"),
@@ -25,8 +30,8 @@ for name, N, M, D, kind in [("C2", 100000, 1024, 16, "RBF"), ("Cm", 100000, 2048
     t_l = timeit(h.sparse_lml)
     t_g = timeit(h.sparse_lml_grad)
     h.sparse_posterior()
-    t_p = timeit(lambda: h.predict_train(True, True), 2)
-    t_pg = timeit(lambda: h.predict_train_gram(True), 2)
+    t_p = timeit(lambda: h.predict_train(True, True), 3)
+    t_pg = timeit(lambda: h.predict_train_gram(True), 3)
     print("%-28s N=%d M=%d D=%d %s: bound %.2f ms (%.1f/s), bound+grad %.2f ms (%.1f/s), predict+predict_gradient on N rows %.1f ms "
           "(N x D Jacobian copied to the host; %.1f ms with its D x D Gram matrix reduced on the device instead, as the EDR loop takes it)"
           % (name, N, M, D, kind, t_l, 1e3 / t_l, t_g, 1e3 / t_g, t_p, t_pg), flush=True)
