@@ -101,6 +101,78 @@ int k_from_r2(Ctx* c, const double* R2, int64_t rows, int M, const double* il2_d
     return EDRGP_OK;
 }
 
+// The same pass for a GROUP of up to SW_GZ length-scales: R2 is read once, every K_z of the group written and its
+// column sums K_z^T y left in bpart[z][row tile][column].  (One R2 read per scale made the pass 3.2 GB per scale at
+// config 4's unit shape; four scales per read: 2.0 GB.)  RBF grids whose K_g are all kept.
+constexpr int SW_GZ = 4;
+__global__ __launch_bounds__(256) void k_from_r2_group_kernel(const double* __restrict__ R2, int64_t rows, int M,
+                                                             const double* __restrict__ il2, int nz, double var, int kind,
+                                                             const double* __restrict__ y, double* __restrict__ K,
+                                                             long long strideK, double* __restrict__ bpart,
+                                                             long long strideB) {
+    const int c0 = ((int)blockIdx.x * 256 + (int)threadIdx.x) * 2;
+    const int64_t r0 = (int64_t)blockIdx.y * 64;
+    if (c0 >= M) return;
+    const bool two = (c0 + 1 < M);
+    const bool vec = two && ((M & 1) == 0);
+    double sz[SW_GZ], b0[SW_GZ], b1[SW_GZ];
+#pragma unroll
+    for (int z = 0; z < SW_GZ; ++z) {
+        sz[z] = (z < nz) ? il2[z] : 0.0;
+        b0[z] = b1[z] = 0.0;
+    }
+    const int nr = (int)min((int64_t)64, rows - r0);
+    for (int r = 0; r < nr; ++r) {
+        const size_t off = (size_t)(r0 + r) * M + c0;
+        double q0, q1 = 0.0;
+        if (vec) {
+            const double2 q = *reinterpret_cast<const double2*>(R2 + off);
+            q0 = q.x; q1 = q.y;
+        } else {
+            q0 = R2[off];
+            if (two) q1 = R2[off + 1];
+        }
+        const double yr = y[r0 + r];
+#pragma unroll
+        for (int z = 0; z < SW_GZ; ++z) {
+            if (z >= nz) break;
+            double k0, k1 = 0.0, h;
+            edrgp_kfun(kind, var, q0 * sz[z], k0, h);
+            if (two) edrgp_kfun(kind, var, q1 * sz[z], k1, h);
+            double* Kz = K + (long long)z * strideK;
+            if (vec) {
+                *reinterpret_cast<double2*>(Kz + off) = double2{k0, k1};
+            } else {
+                Kz[off] = k0;
+                if (two) Kz[off + 1] = k1;
+            }
+            b0[z] = fma(k0, yr, b0[z]);
+            b1[z] = fma(k1, yr, b1[z]);
+        }
+    }
+#pragma unroll
+    for (int z = 0; z < SW_GZ; ++z) {
+        if (z >= nz) break;
+        double* bp = bpart + (long long)z * strideB + (size_t)blockIdx.y * M + c0;
+        bp[0] = b0[z];
+        if (two) bp[1] = b1[z];
+    }
+}
+
+// K_z (z < nz <= SW_GZ; stride strideK) and b_z = K_z^T y (bvecs + z * strideBvec) out of one pass over R2
+int k_from_r2_group(Ctx* c, const double* R2, int64_t rows, int M, const double* il2_dev, int nz, double var, int kind,
+                    const double* y, double* K, long long strideK, double* bvecs, long long strideBvec) {
+    const int tiles_r = (int)((rows + 63) / 64);
+    const long long strideB = (long long)tiles_r * M;
+    TRY(c->bpart.reserve((size_t)nz * strideB * sizeof(double)));
+    dim3 grid((unsigned)((M + 511) / 512), (unsigned)tiles_r, 1);
+    hipLaunchKernelGGL(k_from_r2_group_kernel, grid, dim3(256), 0, c->stream, R2, rows, M, il2_dev, nz, var, kind, y, K, strideK,
+                       c->bpart.d(), strideB);
+    HIP_TRY(hipGetLastError());
+    for (int z = 0; z < nz; ++z) TRY(col_reduce(c, c->bpart.d() + (size_t)z * strideB, tiles_r, M, bvecs + (long long)z * strideBvec));
+    return EDRGP_OK;
+}
+
 __global__ void fill_ones_kernel(double* __restrict__ p, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 1.0;
@@ -212,13 +284,21 @@ int sweep_scales(Ctx* c, int G, const double* ls, double var, double noise_var, 
 
     // ---- row passes, back to back
     for (int g = 0; g < G; ++g) {
-        if (mode[g] < 0) continue;
         // RBF: h(r) = -k(r), the kept K_g serves the gradient pass; Matern: K_g is scratch and h(r) is what is kept
         double* Kg = (keep_k && rbf) ? c->sw_kall.d() + (size_t)g * k_stride : c->Knm.d();
         double* Hg = (keep_k && !rbf) ? c->sw_kall.d() + (size_t)g * k_stride : nullptr;
         double* Phi = PhiB + (size_t)g * phi_stride;
         double* bvec = Phi + MM;
-        {
+        // the kept K_g of an RBF grid are built SW_GZ scales per pass over R2, a scale that is left to the per-unit path
+        // included (b_g = K_g^T y with them: used by the Gram-form scales, overwritten by the stable form's product for
+        // the others)
+        if (keep_k && rbf && g % SW_GZ == 0) {
+            ProfScope ps(c, EDRGP_PROF_KBUILD);
+            TRY(k_from_r2_group(c, R2nm, N, M, il2 + g, std::min(SW_GZ, G - g), var, kind, c->y.d(), Kg, (long long)k_stride,
+                                bvec, (long long)phi_stride));
+        }
+        if (mode[g] < 0) continue;
+        if (!(keep_k && rbf)) {
             ProfScope ps(c, EDRGP_PROF_KBUILD);
             TRY(k_from_r2(c, R2nm, N, M, il2 + g, 1, var, kind, 0.0, mode[g] == 1 ? c->y.d() : nullptr, Kg, 0,
                           mode[g] == 1 ? bvec : nullptr, Hg));
