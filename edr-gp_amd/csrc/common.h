@@ -170,6 +170,7 @@ int diag_mean(Ctx* c, const double* A, int n, int lda, double* out);
 int diag_minmax(Ctx* c, const double* A, int n, int lda, double* out2);   // out2 = {min, max} of diag
 int frob_sq(Ctx* c, const double* A, int n, int lda, double* out);       // sum of squares n x n
 int col_reduce(Ctx* c, const double* part, int nparts, int n, double* out); // out[j] = sum_p part[p][j]
+int col_sums(Ctx* c, const double* A, int64_t rows, int n, double* out);      // out[j] = sum_r A[r][j], A rows x n (uses c->red)
 // C = a*A + b*B + g * w w^T  (n x n, all ld = n)
 int combine3(Ctx* c, int n, double a, const double* A, double b, const double* B, double cc,
              const double* Cm, double g, const double* w, double* out);

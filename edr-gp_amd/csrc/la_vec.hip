@@ -102,6 +102,38 @@ int gemv_t(Ctx* c, int M, int N, double alpha, const double* A, int lda, const d
     return EDRGP_OK;
 }
 
+// Column sums of a tall rows x n matrix (ld = n): 1024-row blocks leave partial sums (fixed order inside a block: four
+// row groups of four accumulators each), col_reduce folds them.  (The Gram-matrix GEMM against a ones vector that did
+// this for the mean Jacobian cost a 32 us launch and a 50 us slab reduction per call.)
+__global__ __launch_bounds__(256) void col_partial_kernel(const double* __restrict__ A, int64_t rows, int n,
+                                                         double* __restrict__ part) {
+    __shared__ double red[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int j = blockIdx.y * 64 + lane;
+    const int64_t r0 = (int64_t)blockIdx.x * 1024, r1 = min(rows, r0 + 1024);
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    if (j < n) {
+        int64_t r = r0 + grp;
+        for (; r + 12 < r1; r += 16) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] += A[(size_t)(r + 4 * u) * n + j];
+        }
+        for (int u = 0; r < r1; r += 4, ++u) a[u] += A[(size_t)r * n + j];
+    }
+    red[grp][lane] = (a[0] + a[1]) + (a[2] + a[3]);
+    __syncthreads();
+    if (grp == 0 && j < n) part[(size_t)blockIdx.x * n + j] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+int col_sums(Ctx* c, const double* A, int64_t rows, int n, double* out) {
+    const int nb = (int)((rows + 1023) / 1024);
+    TRY(c->red.reserve((size_t)nb * n * sizeof(double)));
+    hipLaunchKernelGGL(col_partial_kernel, dim3((unsigned)nb, (unsigned)((n + 63) / 64)), dim3(256), 0, c->stream, A, rows, n,
+                       c->red.d());
+    HIP_TRY(hipGetLastError());
+    return col_reduce(c, c->red.d(), nb, n, out);
+}
+
 int col_reduce(Ctx* c, const double* part, int nparts, int n, double* out) {
     hipLaunchKernelGGL(col_reduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, c->stream, part, nparts, n, 1.0,
                        out);

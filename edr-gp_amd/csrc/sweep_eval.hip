@@ -368,10 +368,8 @@ int sweep_scales(Ctx* c, int G, const double* ls, double var, double noise_var, 
     // ---- gradient Gram matrices: J = d mean / d x at the training rows (one N x D x M product on K_g, or on h_g(r))
     double* d_gram = nullptr;
     if (grams != nullptr) {
-        TRY(c->g2.reserve(((size_t)G * ((size_t)D * D + D) + (size_t)N + 8) * sizeof(double)));
+        TRY(c->g2.reserve(((size_t)G * ((size_t)D * D + D) + 8) * sizeof(double)));
         d_gram = c->g2.d();
-        double* d_ones = d_gram + (size_t)G * ((size_t)D * D + D);
-        hipLaunchKernelGGL(fill_ones_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, d_ones, N);
         const int Wd = 2 * D + 1;
         TRY(c->W.reserve((size_t)(N + 16) * M * sizeof(double)));
         TRY(c->T.reserve((size_t)N * (Wd + D + 2) * sizeof(double)));
@@ -395,7 +393,7 @@ int sweep_scales(Ctx* c, int G, const double* ls, double var, double noise_var, 
             TRY(predict_chunk(c, ks, c->X.d(), N, c->Z.d(), c->Zt.d(), M, vecs + (size_t)g * 4 * M + 3 * M, nullptr, var, Kg,
                               c->W.d(), GT, nullptr, nullptr, o_jac, true, rbf ? nullptr : Kg, !rbf));
             TRY(gemm(c, true, false, D, D, (int)N, 1.0, o_jac, D, o_jac, D, 0.0, Gg, D));
-            TRY(gemm(c, true, false, D, 1, (int)N, 1.0, o_jac, D, d_ones, 1, 0.0, Gg + (size_t)D * D, 1));
+            TRY(col_sums(c, o_jac, N, D, Gg + (size_t)D * D));
         }
     }
 
