@@ -230,11 +230,6 @@ static int dense_eval(Ctx* c, bool need_grad, bool need_post, DenseOut* out) {
 }
 
 // Prediction on a device-resident block of inputs; outputs to host pointers.
-__global__ void fill_ones_kernel(double* __restrict__ p, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = 1.0;
-}
-
 // gram_h / gsum_h (optional): the D x D outer-product matrix J^T J of the posterior-mean gradients and
 // their column sums, accumulated on the device chunk by chunk -- what the EDR step and the candidate
 // sweep (BASELINE config 4) consume -- so the N x D gradient matrix need not cross PCIe.
@@ -272,10 +267,9 @@ static int predict_rows(Ctx* c, const double* Xs_dev, int64_t Ns, double* mean_h
     double* d_gram = nullptr;
     double* d_ones = nullptr;
     if (want_gram) {
-        TRY(c->g2.reserve(((size_t)D * D + D + (size_t)chunk + 8) * sizeof(double)));
+        TRY(c->g2.reserve(((size_t)D * D + 2 * (size_t)D + 8) * sizeof(double)));
         d_gram = c->g2.d();
-        d_ones = d_gram + (size_t)D * D + D;
-        hipLaunchKernelGGL(fill_ones_kernel, dim3((unsigned)((chunk + 255) / 256)), dim3(256), 0, c->stream, d_ones, chunk);
+        d_ones = d_gram + (size_t)D * D + D;              // D doubles of scratch: a later chunk's column sums
     }
     auto slot_jac = [&](int64_t k) { return GT + (size_t)chunk * Wd + (size_t)(k & 1) * slot_doubles; };
     auto compute = [&](int64_t k) -> int {
@@ -289,7 +283,13 @@ static int predict_rows(Ctx* c, const double* Xs_dev, int64_t Ns, double* mean_h
                           want_h ? (h_train ? c->Hnm.d() + (size_t)r0 * Mp : c->Hnm.d()) : nullptr, h_train));
         if (want_gram) {
             TRY(gemm(c, true, false, D, D, (int)rows, 1.0, o_jac, D, o_jac, D, r0 > 0 ? 1.0 : 0.0, d_gram, D));
-            TRY(gemm(c, true, false, D, 1, (int)rows, 1.0, o_jac, D, d_ones, 1, r0 > 0 ? 1.0 : 0.0, d_gram + (size_t)D * D, 1));
+            // column sums of J: a two-stage reduction (la_vec.hip) instead of a GEMM against a ones vector
+            if (r0 == 0) {
+                TRY(col_sums(c, o_jac, rows, D, d_gram + (size_t)D * D));
+            } else {
+                TRY(col_sums(c, o_jac, rows, D, d_ones));
+                TRY(vec_axpy(c, D, 1.0, d_ones, d_gram + (size_t)D * D));
+            }
         }
         HIP_TRY(hipEventRecord(c->ev_pred[k & 1], c->stream));
         return EDRGP_OK;
