@@ -564,6 +564,37 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
             zn[y] = (col < g.N) ? f.zn[col] : 0.0;
             bsum[y] = 0.0;
         }
+        // interior tiles that do not touch the diagonal of a square build: wave-uniform row base + one per-lane byte
+        // offset, no guards (the build is bound by its epilogue's VALU work, not by the two k-tiles of its product)
+        const bool interior = (m0 + BM <= Meff) && (n0 + BN <= g.N) && !(f.same && m0 < n0 + BN && n0 < m0 + BM) && f.dbg == 0 &&
+                              ((long long)BM * g.ldc < (1LL << 28)) && (f.H == nullptr || (long long)BM * f.ldh < (1LL << 28));
+        if (interior) {
+            const int wu = __builtin_amdgcn_readfirstlane(wave);
+            const int wmu = wu >> 1, wnu = wu & 1;
+            char* Cb = reinterpret_cast<char*>(C + (size_t)(m0 + wmu * WM) * g.ldc + n0 + wnu * WN);
+            char* Hb = (f.H != nullptr) ? reinterpret_cast<char*>(f.H + (size_t)(m0 + wmu * WM) * f.ldh + n0 + wnu * WN) : nullptr;
+            const unsigned vc = (unsigned)((lq * g.ldc + lr) * 8), vh = (unsigned)((lq * f.ldh + lr) * 8);
+            const double* xnb = f.xn + m0 + wmu * WM;
+            const double* yb = (f.y != nullptr) ? f.y + m0 + wmu * WM : nullptr;
+#pragma unroll
+            for (int x = 0; x < TM; ++x)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    char* cr = Cb + (size_t)(x * 16 + 4 * r) * g.ldc * 8;
+                    const double xn = xnb[x * 16 + 4 * r + lq];
+                    const double yr = (yb != nullptr) ? yb[x * 16 + 4 * r + lq] : 0.0;
+#pragma unroll
+                    for (int y = 0; y < TN; ++y) {
+                        const double r2 = fmax(fma(-2.0, acc[x][y][r], xn + zn[y]), 0.0);
+                        double Kv, hv;
+                        edrgp_kfun(f.kind, f.var, r2, Kv, hv);
+                        *reinterpret_cast<double*>(cr + vc + y * 128) = Kv;
+                        if (Hb != nullptr)
+                            *reinterpret_cast<double*>(Hb + (size_t)(x * 16 + 4 * r) * f.ldh * 8 + vh + y * 128) = (r2 == 0.0) ? 0.0 : hv;
+                        bsum[y] = fma(Kv, yr, bsum[y]);
+                    }
+                }
+        } else
 #pragma unroll
         for (int x = 0; x < TM; ++x)
 #pragma unroll
