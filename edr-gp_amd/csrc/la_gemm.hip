@@ -1101,7 +1101,9 @@ int gemm(Ctx* c, bool transA, bool transB, int M, int N, int K, double alpha, co
          const double* B, int ldb, double beta, double* C, int ldc, const GemmOpts& o) {
     // split-K only for long-K, small-output, unbatched products (e.g. T^T [X|1|X^2])
     int splits = 1;
-    if (o.batch == 1 && !o.tri) {
+    // (never for a product with a fused epilogue: its tiles are finished in one piece -- a gradient contraction's last,
+    //  partly filled round at M >= 4096 has < 256 tiles and >= 256 k-tiles and used to be refused for that)
+    if (o.batch == 1 && !o.tri && o.fuse == nullptr && o.fusek == nullptr) {
         const int tile = (o.force_tile > 0 ? o.force_tile : 64);
         const long long nt = (long long)((M + tile - 1) / tile) * ((N + tile - 1) / tile);
         const int kt = (K + BK - 1) / BK;

@@ -230,3 +230,27 @@ def test_random_large_shapes_against_oracle(hip):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz"))
     import fuzz
     assert fuzz.run(hip, seed=5, n_cases=3, modes=(0, 0, 2), verbose=True, large=True) == []
+
+
+def test_small_last_round_of_the_contraction_at_m4096(hip):
+    """M = 4096 (256 k-tiles) with a row count whose gradient contraction ends in a partly filled round of fewer than
+    256 tiles -- as one resident chunk and as chunks whose last one is only that round: the generic split-K rule used
+    to claim such a launch and the fused epilogue refused it (EDRGP_ERR_INVALID instead of gradients)."""
+    N, M, D = 131072 + 3 * 128, 4096, 8
+    X, y, Z = synthetic(N, D, M, seed=9)
+    hip.set_data(X, y)
+    hip.set_inducing(Z)
+    hip.set_kernel(["RBF"], [1.0], np.full((1, D), 0.7 * np.sqrt(D)), 0.05)
+    out = {}
+    try:
+        for chunk in (0, 65536):
+            hip.set_option("chunk_rows", chunk)
+            out[chunk] = hip.sparse_lml_grad()
+    finally:
+        hip.set_option("chunk_rows", 0)
+    a, b = out[0], out[65536]
+    assert np.isfinite(a[0]) and abs(a[0] - b[0]) <= 1e-10 * abs(b[0])
+    assert np.abs(a[2] - b[2]).max() <= 1e-7 * np.abs(b[2]).max()
+    # (4096 inducing points in 8 dimensions: dZ cancels ~3 digits more than the bound, and the two chunkings sum in
+    #  different orders)
+    assert np.abs(a[4] - b[4]).max() <= 1e-5 * np.abs(b[4]).max()

@@ -14,6 +14,8 @@ res = {}
 for prec in (32, 64):
     h.set_option("precision", prec)
     h.set_option("profile", 1)
+    if "CHUNK_ROWS" in os.environ:
+        h.set_option("chunk_rows", float(os.environ["CHUNK_ROWS"]))
     if "F32_GUARD" in os.environ:
         h.set_option("f32_guard", float(os.environ["F32_GUARD"]))
     h.set_data(X, y); h.set_inducing(Z)
