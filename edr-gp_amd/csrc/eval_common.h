@@ -116,6 +116,14 @@ int ensure_mats(Ctx* c, int n, int count);
 int stable_product(Ctx* c, const double* K, int64_t rows, int M, const double* Li, const double* y, double* W, double* b);
 int dense_kernel_gradients(Ctx* c, const double* dK, double* Tn, std::vector<double>* dvar, std::vector<double>* dlen);
 
+// The pivot-ratio limit of the automatic statistics form for M inducing points: "pivot_ratio_max" up to M = 2048, tighter
+// above it.  The Gram form's bound error was fitted over 237 large random shapes (tests/fuzz/fuzz_shapes.py) as
+// proxy^2.1 M^1.2 (N^0.2 beta^0.3): equal error means a limit ~ M^-0.6.  (M = 4096: 79 -- config 5, proxy 27, keeps the
+// Gram form; the fuzz's largest error, 7e-10 against the oracle at M = 4216 and proxy 86, now takes the stable one.)
+inline double pivot_ratio_limit(const Ctx* c, int M) {
+    return (M > 2048) ? c->pivot_ratio_max * std::pow(2048.0 / (double)M, 0.6) : c->pivot_ratio_max;
+}
+
 // jitchol's jitter ladder: level -1 = none, level k = mean(diag) * 1e-6 * 10^k
 inline double jit_amount(int level, double diag_mean_) {
     if (level < 0) return 0.0;

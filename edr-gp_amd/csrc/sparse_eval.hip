@@ -430,7 +430,7 @@ struct SparseEval {
         return pr * pr;
     }
     bool rule_says_stable() const {
-        return (c->stats_mode == 2) || (c->stats_mode == 0 && pivot_ratio2() > c->pivot_ratio_max);
+        return (c->stats_mode == 2) || (c->stats_mode == 0 && pivot_ratio2() > pivot_ratio_limit(c, Mr));
     }
 
     void set_bound() {
@@ -928,7 +928,7 @@ struct SparseEval {
         const bool stable64 = rule_says_stable();
         // K_nm S2 in fp32 cancels catastrophically once Kmm is ill conditioned (S2 carries Kmm^-1): the fp32
         // gradient contraction is used only where the Gram form itself is considered safe
-        if (stable64 || pr2 > c->pivot_ratio_max) g32 = false;
+        if (stable64 || pr2 > pivot_ratio_limit(c, Mr)) g32 = false;
         stable = !f32 && stable64;
         c->last_mode = f32 ? 3 : (stable ? 2 : 1);
         tr.mark("phase1 (+queued phase2)");

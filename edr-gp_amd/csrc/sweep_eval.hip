@@ -279,7 +279,7 @@ int sweep_scales(Ctx* c, int G, const double* ls, double var, double noise_var, 
     for (int g = 0; g < G; ++g) {
         const double pr = h_scal[(size_t)g * SW_SLOTS + SW_DIAGMAX] / h_scal[(size_t)g * SW_SLOTS + SW_DIAGMIN];
         if (h_info[g] != 0) mode[g] = -1;
-        else mode[g] = ((c->stats_mode == 2) || (c->stats_mode == 0 && pr * pr > c->pivot_ratio_max)) ? 2 : 1;
+        else mode[g] = ((c->stats_mode == 2) || (c->stats_mode == 0 && pr * pr > pivot_ratio_limit(c, M))) ? 2 : 1;
     }
 
     // ---- row passes, back to back

@@ -88,7 +88,8 @@ int  edrgp_sync(edrgp_ctx* ctx);
  *                     arrays fit into half of the free device memory (and N M < 2^31), else 131072
  *  "stats_mode"       form of the row statistics: 0 automatic (pivot-ratio rule), 1 Gram form Phi = K_mn K_nm,
  *                     2 stable form via K_nm Lm^-T (GPy's operation order)
- *  "pivot_ratio_max"  automatic mode takes the stable form when (max / min diag Lm)^2 exceeds this (default 120)
+ *  "pivot_ratio_max"  automatic mode takes the stable form when (max / min diag Lm)^2 exceeds this (default 120; above
+ *                     2048 inducing points the limit is this times (2048 / M)^0.6)
  *  "precision"        64 (default) or 32 = BASELINE config 5: K_nm stored in fp32 and the gradient contraction
  *                     T = (K_nm S2 + ..) .* h(r), T^T [X | X.^2] on the fp32 MFMA with fp64 slab sums, for single-part
  *                     kernels with D <= 64 while Kmm is conditioned for the Gram form; the bound itself stays fp64
