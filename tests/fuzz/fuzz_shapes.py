@@ -15,7 +15,8 @@ def one_case(h, rng, verbose=False):
     N = int(rng.integers(max(M, 2000), 160000 if M > 2300 else 260000))
     D = int(rng.integers(1, 65))
     kind = KINDS[int(rng.integers(0, 3))]
-    desc = dict(N=N, M=M, D=D, kind=kind)
+    kinds = [kind] if rng.random() < 0.75 else [kind, KINDS[int(rng.integers(0, 3))]]      # every 4th: a sum kernel
+    desc = dict(N=N, M=M, D=D, kind="+".join(kinds))
     X = rng.standard_normal((N, D))
     y = np.tanh(X @ (np.ones(D) / np.sqrt(D))) + 0.05 * rng.standard_normal(N)
     y = (y - y.mean()) / y.std()
@@ -25,7 +26,7 @@ def one_case(h, rng, verbose=False):
     h.set_inducing(Z)
     var, noise = float(0.5 + rng.random()), float(0.005 + 0.1 * rng.random())
     desc.update(ls=round(ls, 3), var=round(var, 3), noise=round(noise, 4))
-    h.set_kernel([kind], [var], np.full((1, D), ls), noise)
+    h.set_kernel(kinds, [var / len(kinds)] * len(kinds), np.array([[ls * (1.0 + 0.4 * p)] * D for p in range(len(kinds))]), noise)
     chunk = int(rng.integers(max(64, N // 9), N))
     desc["chunk"] = chunk
     bad = {}
@@ -41,11 +42,18 @@ def one_case(h, rng, verbose=False):
             mu, jac = h.predict(X[:300], want_var=False)[0], h.predict_grad(X[:300])
             res[name] = (g, b, mu, jac, int(h.get("MODE", (1,))[0]))
             h.set_option("stats_mode", 0)
+        if len(kinds) == 1:
+            # the fp32 row pass (precision 32) on the same problem: never refused, same (fp64) bound, gradients close
+            h.set_option("precision", 32)
+            g32 = h.sparse_lml_grad()
+            h.set_option("precision", 64)
+            res["fp32"] = g32
     except Exception as e:                                      # a refusal or a failed factorisation is a finding
         bad["error"] = "%s: %s" % (type(e).__name__, str(e)[:200])
     finally:
         h.set_option("chunk_rows", 0)
         h.set_option("stats_mode", 0)
+        h.set_option("precision", 64)
     if not bad:
         ref = res["resident"]
         desc["mode"] = ref[4]
@@ -56,6 +64,18 @@ def one_case(h, rng, verbose=False):
             desc["li_frob2"] = float(np.sum(Li * Li))
             desc["li_row2max"] = float(np.max(np.sum(Li * Li, axis=1)))
             desc["gram_vs_stable_abs"] = float(abs(res["stable"][0][0] - ref[0][0])) if ref[4] == 1 else None
+            if ref[4] == 1:
+                h.set_option("stats_mode", 1)
+                h.sparse_lml()
+                Phi = h.get("PHI", (M, M))
+                A = h.get("A", (M, M))
+                LB = h.get("LB", (M, M))
+                h.set_option("stats_mode", 0)
+                desc["phi_frob"] = float(np.sqrt(np.sum(Phi * Phi)))
+                desc["phi_trace"] = float(np.trace(Phi))
+                desc["a_trace"] = float(np.trace(A))
+                desc["lb_diag_min"] = float(np.min(np.diag(LB)))
+                desc["kmmi_frob"] = float(np.sqrt(np.sum((Li.T @ Li) ** 2))) if M <= 2500 else None
         rel = lambda a, b: float(np.abs(np.asarray(a) - np.asarray(b)).max() / (np.abs(np.asarray(b)).max() + 1e-300))
         for name in ("chunked", "stable"):
             r = res[name]
@@ -73,6 +93,16 @@ def one_case(h, rng, verbose=False):
             for k, e in errs.items():
                 if not (e <= tol[k]):
                     bad["%s.%s" % (name, k)] = float(e)
+    if not bad and "fp32" in res:
+        g32, ref = res["fp32"], res["resident"]
+        rel = lambda a, b: float(np.abs(np.asarray(a) - np.asarray(b)).max() / (np.abs(np.asarray(b)).max() + 1e-300))
+        if not np.isfinite(g32[0]) or abs(g32[0] - ref[0][0]) > 1e-9 * max(abs(ref[0][0]), float(N)):
+            bad["fp32.bound"] = float(abs(g32[0] - ref[0][0]) / max(abs(ref[0][0]), float(N)))
+        cs = max(1.0, desc["pr2"] / 1e3)
+        for k, i, t in (("dvar", 1, 5e-2), ("dlen", 2, 5e-2), ("dZ", 4, 5e-1)):
+            e = rel(g32[i], ref[0][i])
+            if not (e <= t * cs):
+                bad["fp32." + k] = e
     if verbose and bad:
         print("FAIL", desc, bad, flush=True)
     return desc, bad
