@@ -96,7 +96,9 @@ def one_case(h, rng, verbose=False):
     if not bad and "fp32" in res:
         g32, ref = res["fp32"], res["resident"]
         rel = lambda a, b: float(np.abs(np.asarray(a) - np.asarray(b)).max() / (np.abs(np.asarray(b)).max() + 1e-300))
-        if not np.isfinite(g32[0]) or abs(g32[0] - ref[0][0]) > 1e-9 * max(abs(ref[0][0]), float(N)):
+        # (the fp64 Phi of precision 32 is that of precision 64 bit for bit unless M is padded to a multiple of 128 in
+        #  one and not in the other: then the two are two summation orders of the Gram form)
+        if not np.isfinite(g32[0]) or abs(g32[0] - ref[0][0]) > 1e-8 * max(abs(ref[0][0]), float(N)):
             bad["fp32.bound"] = float(abs(g32[0] - ref[0][0]) / max(abs(ref[0][0]), float(N)))
         cs = max(1.0, desc["pr2"] / 1e3)
         for k, i, t in (("dvar", 1, 5e-2), ("dlen", 2, 5e-2), ("dZ", 4, 5e-1)):
